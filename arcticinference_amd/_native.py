@@ -1,0 +1,147 @@
+"""ctypes binding of libarctic_hip.so (include/arctic_hip.h).
+
+There is no fallback: if the library is missing this module raises at import of `lib()`, and
+compute entry points raise RuntimeError when no HIP device is visible.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libarctic_hip.so"
+LIB_PATH = os.path.join(_PKG, LIB_NAME)
+CSRC = os.path.join(_PKG, "csrc")
+
+AIC_OK = 0
+AIC_ERR_INVALID, AIC_ERR_NO_DEVICE, AIC_ERR_HIP, AIC_ERR_NOT_FOUND, AIC_ERR_EXISTS, AIC_ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+DT_F32, DT_F16, DT_BF16, DT_FP8_E4M3, DT_FP8_E5M2 = 0, 1, 2, 3, 4
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libarctic_hip: {msg} (status {code})")
+        self.code = code
+
+
+class LstmConfig(ctypes.Structure):
+    _fields_ = [("vocab_size", c_int32), ("vocab_offset", c_int32), ("input_hidden_dim", c_int32),
+                ("inner_dim", c_int32), ("n_predict", c_int32), ("scale_input", c_int32),
+                ("max_batch", c_int32), ("head_fp8_max_batch", c_int32)]
+
+
+class LstmWeights(ctypes.Structure):
+    _fields_ = [("forget_emb", c_void_p), ("proj0", c_void_p), ("proj1", c_void_p), ("cell_ln_w", c_void_p),
+                ("cell_ln_b", c_void_p), ("state_ln_w", c_void_p), ("state_ln_b", c_void_p), ("head", c_void_p),
+                ("head_fp8", c_void_p), ("head_fp8_scale", c_float)]
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", CSRC, "-j8"], stdout=subprocess.DEVNULL)  # incremental
+    return LIB_PATH
+
+
+_SIGNATURES = {
+    # name: (restype, [argtypes])
+    "aic_last_error": (c_char_p, []),
+    "aic_version": (c_int, []),
+    "aic_device_count": (c_int, []),
+    "aic_st_create": (c_void_p, [c_int]),
+    "aic_st_destroy": (None, [c_void_p]),
+    "aic_st_num_seqs": (c_int, [c_void_p]),
+    "aic_st_append": (c_int, [c_void_p, c_int, c_int]),
+    "aic_st_extend": (c_int, [c_void_p, c_int, POINTER(c_int32), c_int]),
+    "aic_st_speculate": (c_int, [c_void_p, POINTER(c_int32), c_int, c_int, c_float, c_float, c_float, c_int,
+                                 POINTER(c_int32), POINTER(c_int32), POINTER(c_float), c_int, POINTER(c_float),
+                                 POINTER(c_int32), c_void_p]),
+    "aic_st_export": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "aic_st_selfcheck": (c_int, [c_void_p]),
+    "aic_sc_create": (c_void_p, [c_int]),
+    "aic_sc_destroy": (None, [c_void_p]),
+    "aic_sc_has_prompt": (c_int, [c_void_p, c_int64]),
+    "aic_sc_cache_prompt": (c_int, [c_void_p, c_int64, c_void_p, c_int]),
+    "aic_sc_cache_prompts": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int]),
+    "aic_sc_evict_prompt": (c_int, [c_void_p, c_int64]),
+    "aic_sc_update_response": (c_int, [c_void_p, c_int64, c_void_p, c_int]),
+    "aic_sc_speculate_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p]),
+    "aic_sc_last_stats": (c_int, [c_void_p, POINTER(c_float), POINTER(c_int64), POINTER(c_int64)]),
+    "aic_sc_global_tree": (c_void_p, [c_void_p]),
+    "aic_sc_prompt_tree": (c_void_p, [c_void_p, c_int64]),
+    "aic_reshape_and_cache_flash_bulk": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_void_p,
+                                                 c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int,
+                                                 c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
+    "aic_rejection_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "aic_rejection_greedy": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                     c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "aic_rejection_random": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p]),
+    "aic_lstm_create": (c_int, [POINTER(LstmConfig), POINTER(LstmWeights), POINTER(c_void_p)]),
+    "aic_lstm_destroy": (None, [c_void_p]),
+    "aic_quantize_fp8_per_tensor": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "aic_lstm_padding_size": (c_int, [c_int]),
+    "aic_lstm_propose": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "aic_lstm_begin": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "aic_lstm_head": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "aic_verify_attention_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "aic_verify_attention": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
+                                     c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                     c_int, c_float, c_void_p, c_int64, c_void_p, c_size_t, c_int, c_void_p]),
+    "aic_ulysses_pack_qkv": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int,
+                                     c_int, c_int, c_void_p]),
+    "aic_ulysses_split_qkv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "aic_ulysses_unpack_out": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `make -C {CSRC}` "
+                              "(or __graft_entry__.build()); there is no fallback implementation")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code: int) -> int:
+    """Raise on a negative status; non-negative values pass through."""
+    if code < 0:
+        msg = lib().aic_last_error().decode("utf-8", "replace")
+        if code == AIC_ERR_NOT_FOUND or code == AIC_ERR_EXISTS:
+            raise ValueError(msg)
+        raise NativeError(code, msg)
+    return code
+
+
+def current_stream_ptr() -> int:
+    import torch
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def torch_dtype_code(dtype) -> int:
+    import torch
+    table = {torch.float32: DT_F32, torch.float16: DT_F16, torch.bfloat16: DT_BF16}
+    for name, code in (("float8_e4m3fn", DT_FP8_E4M3), ("float8_e5m2", DT_FP8_E5M2)):
+        if hasattr(torch, name):
+            table[getattr(torch, name)] = code
+    if dtype not in table:
+        raise NativeError(AIC_ERR_UNSUPPORTED, f"unsupported dtype {dtype}")
+    return table[dtype]

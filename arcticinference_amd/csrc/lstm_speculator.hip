@@ -1,0 +1,739 @@
+// A7-A11 — Arctic LSTM speculator (method "sum_lstm") draft loop on MI355X.
+//
+// Reference (read as text, vLLM is not importable):
+//   ArcticLSTMSpeculator.generate_states / generate_token_ids / generate_proposals
+//     /root/reference/arctic_inference/vllm/spec_dec/arctic_speculator.py:648-691, :706-751, :753-866
+//   MLPSpeculatorLayerNorm.forward  :88-95     LogitsProcessorOpt._get_logits logits_processor_opt.py:83-107
+//   OriginalFp8LinearMethod (per-tensor W8A8, dynamic activation scale) fp8.py:207-223, :276-308
+//   hidden-state pick  arctic_proposer.py:133-147
+// The reference runs ~15 eager torch ops per head and hides the launches in a CUDA graph; every op
+// rounds to bf16.  Here a head is five launches, the elementwise chain is one kernel, and the
+// per-op bf16 roundings of the reference are kept (r() below) so draft tokens agree.
+//
+// Cost model (Llama-3.1-8B speculator, Ds = H = 4096, V = 128256, k = 3, B <= 64): per head the
+// gate projection streams 4Ds x K bf16 = 134 MB and the LM head V x Ds = 525 MB (fp8) / 1.05 GB
+// (bf16) -> HBM-bound skinny GEMMs (M = padded batch <= 64, ridge far away), MFMA only because
+// 2*M*N*K at M=64 exceeds the vector ALU rate.  Design for that bound:
+//   * weights are re-laid out once at load into MFMA-fragment-major tiles: the A fragment of
+//     (16 weight rows x 32 k) is one contiguous 1 KiB chunk, 16 B per lane -> every weight load is
+//     a perfectly coalesced 1 KiB wave instruction streaming a 128 KiB contiguous run per row tile;
+//     loads go straight to VGPRs one K-chunk ahead (8 KiB per wave in flight, 64 KiB per CU at
+//     2 workgroups/CU);
+//   * activations (<= 512 KiB, L2 resident) are kept fragment-major as well, copied linearly into a
+//     double-buffered LDS chunk shared by the 4 waves of a workgroup and read with conflict-free
+//     ds_read_b128;
+//   * the LM head never materialises [B, V] logits: bf16-rounded logits are arg-max-reduced in the
+//     MFMA accumulator layout (4 regs -> 2 shuffles -> LDS across waves) to one (value, index) per
+//     workgroup and batch row.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <vector>
+
+#include "aic_common.h"
+
+namespace aic {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int kChunkSteps = 8;   // k-steps per LDS chunk (bf16: 8 x 32 k = 256; fp8: 8 x 64 k = 512)
+constexpr int kRowsPerBlock = 64;  // 4 waves x one 16-row tile
+
+__device__ __forceinline__ float r(float x) { return round_bf16(x); }
+
+// ---- fragment-major activation layout --------------------------------------------------------
+// bf16: 16-byte unit u = ((k/32) * MT + m/16) * 64 + ((k/8)%4)*16 + m%16 holds k%8 = 0..7
+// fp8 : 16-byte unit u = ((k/64) * MT + m/16) * 64 + ((k/16)%4)*16 + m%16 holds k%16 = 0..15
+__device__ __forceinline__ int64_t xunit_bf16(int m, int k8, int MT) {  // k8 = k / 8
+  return (static_cast<int64_t>(k8 >> 2) * MT + (m >> 4)) * 64 + (k8 & 3) * 16 + (m & 15);
+}
+__device__ __forceinline__ int64_t xunit_fp8(int m, int k16, int MT) {  // k16 = k / 16
+  return (static_cast<int64_t>(k16 >> 2) * MT + (m >> 4)) * 64 + (k16 & 3) * 16 + (m & 15);
+}
+
+// ---- block reductions --------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();  // sh may still be read from a previous reduction
+  if ((threadIdx.x & 63) == 0) sh[wave] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ---- weight repacking (one-time, at load) ------------------------------------------------------
+// dst unit ((rt * KS + ks) * 64 + l) <- src[rt*16 + l%16][ks*32 + 8*(l/16) .. +8]   (bf16)
+__global__ void __launch_bounds__(256)
+repack_bf16_kernel(const uint16_t* __restrict__ src, uint4* __restrict__ dst, int n_rows, int K, int n_rowtiles) {
+  const int KS = K / 32;
+  const int64_t total = static_cast<int64_t>(n_rowtiles) * KS * 64;
+  for (int64_t u = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; u < total;
+       u += static_cast<int64_t>(gridDim.x) * 256) {
+    const int l = static_cast<int>(u & 63);
+    const int64_t t = u >> 6;
+    const int ks = static_cast<int>(t % KS);
+    const int rt = static_cast<int>(t / KS);
+    const int row = rt * 16 + (l & 15);
+    const int col = ks * 32 + 8 * (l >> 4);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < n_rows) v = *reinterpret_cast<const uint4*>(src + static_cast<int64_t>(row) * K + col);
+    dst[u] = v;
+  }
+}
+
+__device__ __forceinline__ uint32_t pack4_fp8(float a, float b, float c, float d) {
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return static_cast<uint32_t>(w);
+}
+__device__ __forceinline__ float clamp448(float x) { return __builtin_amdgcn_fmed3f(x, 448.0f, -448.0f); }
+
+// dst unit ((rt * KP + kp) * 64 + l) <- q(src[rt*16 + l%16][kp*64 + 16*(l/16) .. +16])   (e4m3fn)
+__global__ void __launch_bounds__(256)
+quant_repack_fp8_kernel(const uint16_t* __restrict__ src, uint4* __restrict__ dst, const float* __restrict__ scale,
+                        int n_rows, int K, int n_rowtiles) {
+  const int KP = K / 64;
+  const float inv = 1.0f / *scale;
+  const int64_t total = static_cast<int64_t>(n_rowtiles) * KP * 64;
+  for (int64_t u = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; u < total;
+       u += static_cast<int64_t>(gridDim.x) * 256) {
+    const int l = static_cast<int>(u & 63);
+    const int64_t t = u >> 6;
+    const int kp = static_cast<int>(t % KP);
+    const int rt = static_cast<int>(t / KP);
+    const int row = rt * 16 + (l & 15);
+    const int col = kp * 64 + 16 * (l >> 4);
+    uint4 out = make_uint4(0, 0, 0, 0);
+    if (row < n_rows) {
+      const uint16_t* p = src + static_cast<int64_t>(row) * K + col;
+      uint16_t h[16];
+      *reinterpret_cast<uint4*>(h) = *reinterpret_cast<const uint4*>(p);
+      *reinterpret_cast<uint4*>(h + 8) = *reinterpret_cast<const uint4*>(p + 8);
+      float f[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) f[e] = clamp448(bf16_to_f32(h[e]) * inv);
+      out.x = pack4_fp8(f[0], f[1], f[2], f[3]);
+      out.y = pack4_fp8(f[4], f[5], f[6], f[7]);
+      out.z = pack4_fp8(f[8], f[9], f[10], f[11]);
+      out.w = pack4_fp8(f[12], f[13], f[14], f[15]);
+    }
+    dst[u] = out;
+  }
+}
+
+// |x| maximum of a bf16 array into *amax_bits (non-negative floats order like their bit patterns)
+__global__ void __launch_bounds__(256)
+amax_bf16_kernel(const uint16_t* __restrict__ src, int64_t n, unsigned int* __restrict__ amax_bits) {
+  float m = 0.0f;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * 256)
+    m = fmaxf(m, fabsf(bf16_to_f32(src[i])));
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(m));
+}
+// scale = max(amax / 448, 1 / (448 * 512))   (vLLM dynamic per-tensor scaled_fp8_quant)
+__global__ void finish_scale_kernel(const unsigned int* __restrict__ amax_bits, float* __restrict__ scale) {
+  *scale = fmaxf(__uint_as_float(*amax_bits) / 448.0f, 1.0f / (448.0f * 512.0f));
+}
+__global__ void __launch_bounds__(256)
+quant_rowmajor_fp8_kernel(const uint16_t* __restrict__ src, uint8_t* __restrict__ dst, const float* __restrict__ scale,
+                          int64_t n) {
+  const float inv = 1.0f / *scale;
+  for (int64_t i = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 4; i < n;
+       i += static_cast<int64_t>(gridDim.x) * 256 * 4) {
+    float f[4] = {0, 0, 0, 0};
+    for (int e = 0; e < 4 && i + e < n; ++e) f[e] = clamp448(bf16_to_f32(src[i + e]) * inv);
+    const uint32_t w = pack4_fp8(f[0], f[1], f[2], f[3]);
+    for (int e = 0; e < 4 && i + e < n; ++e) dst[i + e] = static_cast<uint8_t>(w >> (8 * e));
+  }
+}
+
+// ---- head 0 input: ln0(x) / sqrt(2), gathered by hidden_index, fragment-major bf16 ---------------
+// MLPSpeculatorLayerNorm without affine (arctic_speculator.py:88-91) with the reference's per-op
+// bf16 roundings; rows >= batch are zero.  Also clears the per-call device state.
+__global__ void __launch_bounds__(256)
+ln0_kernel(const uint16_t* __restrict__ hidden, const int32_t* __restrict__ hidden_index, int batch, int H, int MT,
+           int scale_input, uint4* __restrict__ x_out, uint16_t* __restrict__ cell, int Ds,
+           unsigned int* __restrict__ amax_bits, int n_amax) {
+  __shared__ float sh[4];
+  const int m = blockIdx.x;
+  if (m == 0 && threadIdx.x < n_amax) amax_bits[threadIdx.x] = 0u;
+  // zero initial cell state (arctic_speculator.py:781-785)
+  for (int j = threadIdx.x * 8; j < Ds; j += 256 * 8)
+    *reinterpret_cast<uint4*>(cell + static_cast<int64_t>(m) * Ds + j) = make_uint4(0, 0, 0, 0);
+  if (m >= batch) {
+    for (int k8 = threadIdx.x; k8 < H / 8; k8 += 256) x_out[xunit_bf16(m, k8, MT)] = make_uint4(0, 0, 0, 0);
+    return;
+  }
+  const int64_t row = hidden_index ? hidden_index[m] : m;
+  const uint16_t* x = hidden + row * H;
+  float ss = 0.0f;
+  if (scale_input) {
+    for (int k8 = threadIdx.x; k8 < H / 8; k8 += 256) {
+      uint16_t h[8];
+      *reinterpret_cast<uint4*>(h) = *reinterpret_cast<const uint4*>(x + k8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = bf16_to_f32(h[e]);
+        ss += r(v * v);  // xf.pow(2) is a bf16 tensor
+      }
+    }
+    ss = block_sum_256(ss, sh);
+  }
+  const float mean = r(ss / static_cast<float>(H));
+  const float rs = r(rsqrtf(r(mean + 1e-6f)));
+  const float inv_sqrt2 = 0.70710678118654752f;
+  for (int k8 = threadIdx.x; k8 < H / 8; k8 += 256) {
+    uint16_t h[8];
+    *reinterpret_cast<uint4*>(h) = *reinterpret_cast<const uint4*>(x + k8 * 8);
+    if (scale_input) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h[e] = f32_to_bf16(r(bf16_to_f32(h[e]) * rs) * inv_sqrt2);
+    }
+    x_out[xunit_bf16(m, k8, MT)] = *reinterpret_cast<uint4*>(h);
+  }
+}
+
+// ---- skinny GEMM: out[m][n] = sum_k X[m][k] * W[n][k],  M = 16*MT <= 64 ---------------------------
+// EPI 0: fp32 partials  part[split][m][n]          (gate projection, split-K over blockIdx.y)
+// EPI 1: arg-max of bf16(acc * scale) over the block's 64 rows -> best_val/best_idx[block][m]
+template <bool FP8, int MT, int EPI>
+__global__ void __launch_bounds__(256, 2)
+skinny_gemm_kernel(const uint4* __restrict__ W, const uint4* __restrict__ X, int n_rowtiles, int steps_total,
+                   int steps_per_split, float* __restrict__ part, int n_cols_out, const float* __restrict__ x_scale,
+                   float w_scale, int n_valid_rows, int row_offset, float* __restrict__ best_val,
+                   int32_t* __restrict__ best_idx) {
+  constexpr int S = kChunkSteps;
+  constexpr int XV = S * MT * 64 / 256;  // uint4 per thread per chunk
+  __shared__ uint4 lds[2][S * MT * 64];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int rt = blockIdx.x * 4 + wave;
+  const int split = blockIdx.y;
+  const int ks0 = split * steps_per_split;
+  const int n_chunks = steps_per_split / S;
+  const bool live = rt < n_rowtiles;
+
+  const uint4* a_ptr = W + (static_cast<int64_t>(live ? rt : 0) * steps_total + ks0) * 64 + lane;
+  const uint4* x_ptr = X + static_cast<int64_t>(ks0) * MT * 64 + tid;
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  uint4 xr[XV];
+  uint4 a0[S], a1[S];
+#pragma unroll
+  for (int i = 0; i < XV; ++i) xr[i] = x_ptr[i * 256];
+#pragma unroll
+  for (int s = 0; s < S; ++s) a0[s] = a_ptr[s * 64];
+#pragma unroll
+  for (int i = 0; i < XV; ++i) lds[0][i * 256 + tid] = xr[i];
+  __syncthreads();
+
+  auto compute = [&](const uint4(&a)[S], int buf) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const uint4 b = lds[buf][(s * MT + mt) * 64 + lane];
+        if (FP8) {
+          const long a_lo = static_cast<long>(a[s].x) | (static_cast<long>(a[s].y) << 32);
+          const long a_hi = static_cast<long>(a[s].z) | (static_cast<long>(a[s].w) << 32);
+          const long b_lo = static_cast<long>(b.x) | (static_cast<long>(b.y) << 32);
+          const long b_hi = static_cast<long>(b.z) | (static_cast<long>(b.w) << 32);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a_lo, b_lo, acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a_hi, b_hi, acc[mt], 0, 0, 0);
+        } else {
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[s]),
+                                                            __builtin_bit_cast(bf16x8, b), acc[mt], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  // two chunks per trip so the weight prefetch ping-pongs between a0 / a1 without register copies
+  for (int c = 0; c < n_chunks; c += 2) {
+    const bool has1 = c + 1 < n_chunks;
+    if (has1) {
+#pragma unroll
+      for (int i = 0; i < XV; ++i) xr[i] = x_ptr[static_cast<int64_t>(c + 1) * S * MT * 64 + i * 256];
+#pragma unroll
+      for (int s = 0; s < S; ++s) a1[s] = a_ptr[(static_cast<int64_t>(c + 1) * S + s) * 64];
+    }
+    compute(a0, 0);
+    if (has1) {
+#pragma unroll
+      for (int i = 0; i < XV; ++i) lds[1][i * 256 + tid] = xr[i];
+    }
+    __syncthreads();
+    if (!has1) break;
+    const bool has2 = c + 2 < n_chunks;
+    if (has2) {
+#pragma unroll
+      for (int i = 0; i < XV; ++i) xr[i] = x_ptr[static_cast<int64_t>(c + 2) * S * MT * 64 + i * 256];
+#pragma unroll
+      for (int s = 0; s < S; ++s) a0[s] = a_ptr[(static_cast<int64_t>(c + 2) * S + s) * 64];
+    }
+    compute(a1, 1);
+    if (has2) {
+#pragma unroll
+      for (int i = 0; i < XV; ++i) lds[0][i * 256 + tid] = xr[i];
+    }
+    __syncthreads();
+  }
+
+  // accumulator layout (16x16): column (batch row) = lane & 15, weight row = (lane >> 4) * 4 + reg
+  const int n0 = rt * 16 + (lane >> 4) * 4;
+  if (EPI == 0) {
+    if (live) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 16 + (lane & 15);
+        float4 v = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+        *reinterpret_cast<float4*>(part + (static_cast<int64_t>(split) * (MT * 16) + m) * n_cols_out + n0) = v;
+      }
+    }
+  } else {
+    // the K loop ended with a barrier: the staging buffer is free to carry the cross-wave reduction
+    float(*s_val)[MT * 16] = reinterpret_cast<float(*)[MT * 16]>(&lds[0][0]);
+    int(*s_idx)[MT * 16] = reinterpret_cast<int(*)[MT * 16]>(&lds[1][0]);
+    const float sc = FP8 ? (*x_scale) * w_scale : 1.0f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      float bv = -INFINITY;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + e;
+        const float v = r(acc[mt][e] * sc);  // logits are a bf16 tensor in the reference
+        if (live && n < n_valid_rows && (v > bv || (v == bv && n < bi))) {
+          bv = v;
+          bi = n;
+        }
+      }
+#pragma unroll
+      for (int off = 16; off <= 32; off <<= 1) {
+        const float ov = __shfl_xor(bv, off);
+        const int oi = __shfl_xor(bi, off);
+        if (ov > bv || (ov == bv && oi < bi)) {
+          bv = ov;
+          bi = oi;
+        }
+      }
+      if (lane < 16) {
+        s_val[wave][mt * 16 + lane] = bv;
+        s_idx[wave][mt * 16 + lane] = bi;
+      }
+    }
+    __syncthreads();
+    if (tid < MT * 16) {
+      float bv = s_val[0][tid];
+      int bi = s_idx[0][tid];
+      for (int w = 1; w < 4; ++w) {
+        const float ov = s_val[w][tid];
+        const int oi = s_idx[w][tid];
+        if (ov > bv || (ov == bv && oi < bi)) {
+          bv = ov;
+          bi = oi;
+        }
+      }
+      best_val[static_cast<int64_t>(blockIdx.x) * (MT * 16) + tid] = bv;
+      best_idx[static_cast<int64_t>(blockIdx.x) * (MT * 16) + tid] = bi == 0x7fffffff ? 0x7fffffff : bi + row_offset;
+    }
+  }
+}
+
+// ---- LSTM cell: everything between the gate projection and the LM head (arctic_speculator.py:667-689)
+// one workgroup per batch row; r() marks every place the reference materialises a bf16 tensor
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__global__ void __launch_bounds__(256)
+lstm_cell_kernel(const float* __restrict__ part, int n_splits, int m_pad, int batch, const int32_t* __restrict__ tokens,
+                 const uint16_t* __restrict__ emb, int vocab_rows, float alpha, const uint16_t* __restrict__ cln_w,
+                 const uint16_t* __restrict__ cln_b, const uint16_t* __restrict__ sln_w,
+                 const uint16_t* __restrict__ sln_b, uint16_t* __restrict__ cell, int Ds, int MT,
+                 uint4* __restrict__ h_out, unsigned int* __restrict__ amax_bits) {
+  extern __shared__ float smem[];  // [Ds] staging of the row between the two normalisations
+  __shared__ float sh[4];
+  const int m = blockIdx.x;
+  if (m >= batch) {
+    for (int k8 = threadIdx.x; k8 < Ds / 8; k8 += 256) h_out[xunit_bf16(m, k8, MT)] = make_uint4(0, 0, 0, 0);
+    return;
+  }
+  const int N = 4 * Ds;
+  int tok = tokens[m];
+  if (tok < 0 || tok >= vocab_rows) tok = 0;  // never read outside the table
+  const uint16_t* z = emb + static_cast<int64_t>(tok) * Ds;
+
+  auto added = [&](int n, int j) -> float {  // torch.add(states, z, alpha=emb_weight / state_weight)
+    float s = 0.0f;
+    for (int sp = 0; sp < n_splits; ++sp) s += part[(static_cast<int64_t>(sp) * m_pad + m) * N + n];
+    return r(fmaf(alpha, bf16_to_f32(z[j]), r(s)));
+  };
+  auto sigmoid = [](float x) -> float { return r(1.0f / (1.0f + expf(-x))); };
+
+  // pass 1: cell candidate pre-activation and its mean square
+  float ss = 0.0f;
+  for (int j = threadIdx.x; j < Ds; j += 256) {
+    const float c = added(3 * Ds + j, j);
+    smem[j] = c;
+    ss += r(c * c);
+  }
+  ss = block_sum_256(ss, sh);
+  float rs = r(rsqrtf(r(r(ss / static_cast<float>(Ds)) + 1e-6f)));
+
+  // pass 2: gates, new cell state, its mean square
+  float ss2 = 0.0f;
+  for (int j = threadIdx.x; j < Ds; j += 256) {
+    float y = r(smem[j] * rs);
+    y = r(bf16_to_f32(cln_w[j]) * y);
+    y = r(y + bf16_to_f32(cln_b[j]));
+    const float cand = r(r(gelu_erf(y)) * sigmoid(added(Ds + j, j)));           // * input gate
+    const float kept = r(bf16_to_f32(cell[static_cast<int64_t>(m) * Ds + j]) * sigmoid(added(j, j)));  // * forget gate
+    const float cnew = r(kept + cand);
+    cell[static_cast<int64_t>(m) * Ds + j] = f32_to_bf16(cnew);
+    smem[j] = cnew;
+    ss2 += r(cnew * cnew);
+  }
+  ss2 = block_sum_256(ss2, sh);
+  rs = r(rsqrtf(r(r(ss2 / static_cast<float>(Ds)) + 1e-6f)));
+
+  // pass 3: state = gelu(state_ln(cell)) * output gate, written fragment-major for the next GEMMs
+  float amax = 0.0f;
+  for (int k8 = threadIdx.x; k8 < Ds / 8; k8 += 256) {
+    uint16_t h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int j = k8 * 8 + e;
+      float y = r(smem[j] * rs);
+      y = r(bf16_to_f32(sln_w[j]) * y);
+      y = r(y + bf16_to_f32(sln_b[j]));
+      const float st = r(r(gelu_erf(y)) * sigmoid(added(2 * Ds + j, j)));  // * output gate
+      h[e] = f32_to_bf16(st);
+      amax = fmaxf(amax, fabsf(st));
+    }
+    h_out[xunit_bf16(m, k8, MT)] = *reinterpret_cast<uint4*>(h);
+  }
+  for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+  if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(amax));
+}
+
+// ---- dynamic per-tensor activation quantisation for the fp8 LM head (fp8.py:303-308) ------------
+__global__ void __launch_bounds__(256)
+quant_act_kernel(const uint4* __restrict__ h_bf16, uint4* __restrict__ h_fp8, const unsigned int* __restrict__ amax_bits,
+                 float* __restrict__ x_scale, int Ds, int MT) {
+  const float scale = fmaxf(__uint_as_float(*amax_bits) / 448.0f, 1.0f / (448.0f * 512.0f));
+  const float inv = 1.0f / scale;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *x_scale = scale;
+  const int total = (Ds / 16) * MT * 16;  // fp8 16-byte units
+  for (int u = blockIdx.x * 256 + threadIdx.x; u < total; u += gridDim.x * 256) {
+    // unit u = ((kp * MT + mt) * 64 + g * 16 + mm) covers k = kp*64 + 16 g .. +16 of row mt*16 + mm
+    const int mm = u & 15, g = (u >> 4) & 3;
+    const int t = u >> 6;
+    const int mt = t % MT, kp = t / MT;
+    const int m = mt * 16 + mm;
+    const int k8 = (kp * 64 + 16 * g) / 8;
+    uint16_t h[16];
+    *reinterpret_cast<uint4*>(h) = h_bf16[xunit_bf16(m, k8, MT)];
+    *reinterpret_cast<uint4*>(h + 8) = h_bf16[xunit_bf16(m, k8 + 1, MT)];
+    float f[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) f[e] = clamp448(bf16_to_f32(h[e]) * inv);
+    uint4 o;
+    o.x = pack4_fp8(f[0], f[1], f[2], f[3]);
+    o.y = pack4_fp8(f[4], f[5], f[6], f[7]);
+    o.z = pack4_fp8(f[8], f[9], f[10], f[11]);
+    o.w = pack4_fp8(f[12], f[13], f[14], f[15]);
+    h_fp8[u] = o;
+  }
+}
+
+// ---- final arg-max over the per-workgroup partials; feeds the next head ---------------------------
+__global__ void __launch_bounds__(256)
+argmax_finish_kernel(const float* __restrict__ best_val, const int32_t* __restrict__ best_idx, int n_blocks, int m_pad,
+                     int batch, int32_t* __restrict__ tokens, int64_t* __restrict__ out_tokens, int out_stride,
+                     int out_col, float* __restrict__ out_vals) {
+  __shared__ float s_v[4];
+  __shared__ int s_i[4];
+  const int m = blockIdx.x;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int b = threadIdx.x; b < n_blocks; b += 256) {
+    const float v = best_val[static_cast<int64_t>(b) * m_pad + m];
+    const int i = best_idx[static_cast<int64_t>(b) * m_pad + m];
+    if (v > bv || (v == bv && i < bi)) {
+      bv = v;
+      bi = i;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(bv, off);
+    const int oi = __shfl_xor(bi, off);
+    if (ov > bv || (ov == bv && oi < bi)) {
+      bv = ov;
+      bi = oi;
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_v[threadIdx.x >> 6] = bv;
+    s_i[threadIdx.x >> 6] = bi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (s_v[w] > bv || (s_v[w] == bv && s_i[w] < bi)) {
+        bv = s_v[w];
+        bi = s_i[w];
+      }
+    if (m < batch) {
+      tokens[m] = bi;
+      if (out_tokens) out_tokens[static_cast<int64_t>(m) * out_stride + out_col] = bi;
+      if (out_vals) out_vals[static_cast<int64_t>(m) * out_stride + out_col] = bv;
+    }
+  }
+}
+
+__global__ void copy_tokens_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+}  // namespace aic
+
+using namespace aic;
+
+struct aic_lstm {
+  aic_lstm_config cfg;
+  aic_lstm_weights w;
+  float alpha;
+  // repacked weights (owned)
+  uint4 *proj0_t = nullptr, *proj1_t = nullptr, *head_t = nullptr, *head8_t = nullptr;
+  float head8_scale = 0.0f;
+  int gate_rowtiles = 0, head_rowtiles = 0, head_blocks = 0;
+  // per-call state (owned)
+  int max_mt = 0;
+  uint4 *x0 = nullptr, *h_bf16 = nullptr, *h_fp8 = nullptr;
+  uint16_t* cell = nullptr;
+  float* part = nullptr;
+  float* best_val = nullptr;
+  int32_t* best_idx = nullptr;
+  int32_t* tokens = nullptr;
+  unsigned int* amax = nullptr;
+  float* x_scale = nullptr;
+  int gate_splits = 2;
+  int cur_mt = 0, cur_batch = 0;
+};
+
+static int pad_mt(int batch) { return batch <= 16 ? 1 : (batch <= 32 ? 2 : 4); }
+
+template <bool FP8, int EPI>
+static int launch_gemm(int mt, dim3 grid, hipStream_t s, const uint4* W, const uint4* X, int rowtiles, int steps_total,
+                       int steps_per_split, float* part, int n_cols, const float* x_scale, float w_scale, int n_valid,
+                       int row_offset, float* bv, int32_t* bi) {
+#define AIC_GEMM(MT)                                                                                              \
+  hipLaunchKernelGGL((skinny_gemm_kernel<FP8, MT, EPI>), grid, dim3(256), 0, s, W, X, rowtiles, steps_total,      \
+                     steps_per_split, part, n_cols, x_scale, w_scale, n_valid, row_offset, bv, bi)
+  if (mt == 1) AIC_GEMM(1);
+  else if (mt == 2) AIC_GEMM(2);
+  else AIC_GEMM(4);
+#undef AIC_GEMM
+  return launch_status("skinny_gemm_kernel");
+}
+
+static int run_head(aic_lstm* m, int head_index, hipStream_t s, int64_t* out_tokens, int out_stride, int out_col,
+                    float* out_vals) {
+  const aic_lstm_config& c = m->cfg;
+  const int mt = m->cur_mt, mpad = mt * 16, B = m->cur_batch;
+  const int Ds = c.inner_dim;
+  int rc;
+  // 1. gate projection (4Ds x K), split-K partials in fp32
+  {
+    const bool first = head_index == 0;
+    const int K = first ? c.input_hidden_dim : Ds;
+    const int steps_total = K / 32;
+    int splits = m->gate_splits;
+    while (splits > 1 && (steps_total % (splits * kChunkSteps) != 0)) --splits;
+    dim3 grid((m->gate_rowtiles + 3) / 4, splits);
+    rc = launch_gemm<false, 0>(mt, grid, s, first ? m->proj0_t : m->proj1_t, first ? m->x0 : m->h_bf16,
+                               m->gate_rowtiles, steps_total, steps_total / splits, m->part, 4 * Ds, nullptr, 1.0f, 0,
+                               0, nullptr, nullptr);
+    if (rc != AIC_OK) return rc;
+    // 2. cell update
+    hipLaunchKernelGGL(lstm_cell_kernel, dim3(mpad), dim3(256), Ds * sizeof(float), s, m->part, splits, mpad, B,
+                       m->tokens, static_cast<const uint16_t*>(m->w.forget_emb), 0x7fffffff, m->alpha,
+                       static_cast<const uint16_t*>(m->w.cell_ln_w), static_cast<const uint16_t*>(m->w.cell_ln_b),
+                       static_cast<const uint16_t*>(m->w.state_ln_w), static_cast<const uint16_t*>(m->w.state_ln_b),
+                       m->cell, Ds, mt, m->h_bf16, m->amax + head_index);
+    if ((rc = launch_status("lstm_cell_kernel")) != AIC_OK) return rc;
+  }
+  // 3. LM head + fused arg-max
+  const bool fp8 = m->head8_t && mpad <= c.head_fp8_max_batch;
+  dim3 hgrid(m->head_blocks, 1);
+  if (fp8) {
+    hipLaunchKernelGGL(quant_act_kernel, dim3(64), dim3(256), 0, s, m->h_bf16, m->h_fp8, m->amax + head_index,
+                       m->x_scale, Ds, mt);
+    if ((rc = launch_status("quant_act_kernel")) != AIC_OK) return rc;
+    rc = launch_gemm<true, 1>(mt, hgrid, s, m->head8_t, m->h_fp8, m->head_rowtiles, Ds / 64, Ds / 64, nullptr, 0,
+                              m->x_scale, m->head8_scale, c.vocab_size, c.vocab_offset, m->best_val, m->best_idx);
+  } else {
+    rc = launch_gemm<false, 1>(mt, hgrid, s, m->head_t, m->h_bf16, m->head_rowtiles, Ds / 32, Ds / 32, nullptr, 0,
+                               nullptr, 1.0f, c.vocab_size, c.vocab_offset, m->best_val, m->best_idx);
+  }
+  if (rc != AIC_OK) return rc;
+  hipLaunchKernelGGL(argmax_finish_kernel, dim3(mpad), dim3(256), 0, s, m->best_val, m->best_idx, m->head_blocks, mpad,
+                     B, m->tokens, out_tokens, out_stride, out_col, out_vals);
+  return launch_status("argmax_finish_kernel");
+}
+
+extern "C" {
+
+int aic_lstm_padding_size(int size) {  // arctic_speculator.py:39-44
+  if (size <= 0) return size;
+  int bits = 0;
+  for (int v = size - 1; v > 0; v >>= 1) ++bits;
+  const int mult = (1 << bits) / 4;
+  if (mult < 1) return size;
+  return (size + mult - 1) / mult * mult;
+}
+
+int aic_quantize_fp8_per_tensor(const void* src_bf16, void* dst_fp8, float* scale_out, int64_t n, void* stream) {
+  AIC_REQUIRE(src_bf16 && dst_fp8 && scale_out && n > 0, "bad arguments to aic_quantize_fp8_per_tensor");
+  AIC_NEED_DEVICE();
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  unsigned int* amax = nullptr;
+  AIC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&amax), 4));
+  AIC_HIP_TRY(hipMemsetAsync(amax, 0, 4, s));
+  const unsigned g = static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, 2048));
+  hipLaunchKernelGGL(amax_bf16_kernel, dim3(g), dim3(256), 0, s, static_cast<const uint16_t*>(src_bf16), n, amax);
+  hipLaunchKernelGGL(finish_scale_kernel, dim3(1), dim3(1), 0, s, amax, scale_out);
+  hipLaunchKernelGGL(quant_rowmajor_fp8_kernel, dim3(g), dim3(256), 0, s, static_cast<const uint16_t*>(src_bf16),
+                     static_cast<uint8_t*>(dst_fp8), scale_out, n);
+  int rc = launch_status("quantize_fp8_per_tensor");
+  AIC_HIP_TRY(hipStreamSynchronize(s));
+  AIC_HIP_TRY(hipFree(amax));
+  return rc;
+}
+
+int aic_lstm_create(const aic_lstm_config* cfg, const aic_lstm_weights* w, aic_lstm** out) {
+  AIC_REQUIRE(cfg && w && out, "null argument to aic_lstm_create");
+  AIC_REQUIRE(cfg->inner_dim > 0 && cfg->inner_dim % 512 == 0, "inner_dim must be a positive multiple of 512");
+  AIC_REQUIRE(cfg->input_hidden_dim > 0 && cfg->input_hidden_dim % 256 == 0,
+              "input_hidden_dim must be a positive multiple of 256");
+  AIC_REQUIRE(cfg->vocab_size > 0 && cfg->n_predict > 0 && cfg->max_batch > 0 && cfg->max_batch <= 64,
+              "vocab_size / n_predict must be positive and max_batch in 1..64");
+  AIC_REQUIRE(w->forget_emb && w->proj0 && w->proj1 && w->cell_ln_w && w->cell_ln_b && w->state_ln_w &&
+                  w->state_ln_b && w->head,
+              "missing weight pointer");
+  AIC_NEED_DEVICE();
+  aic_lstm* m = new aic_lstm();
+  m->cfg = *cfg;
+  m->w = *w;
+  const int Ds = cfg->inner_dim, H = cfg->input_hidden_dim, V = cfg->vocab_size;
+  const double sw = std::pow(0.5, 0.5 / cfg->n_predict);                 // state_weight (:575)
+  const double ew = std::sqrt((1.0 - sw * sw) * (static_cast<double>(Ds) / 2.0));  // emb_weight (:576-577)
+  m->alpha = static_cast<float>(ew / sw);
+  m->gate_rowtiles = 4 * Ds / 16;
+  m->head_blocks = (V + kRowsPerBlock - 1) / kRowsPerBlock;
+  m->head_rowtiles = m->head_blocks * 4;
+  m->max_mt = pad_mt(cfg->max_batch);
+  const int mpad = m->max_mt * 16;
+  const int Kmax = std::max(Ds, H);
+  hipStream_t s = nullptr;
+#define AIC_ALLOC(ptr, bytes) AIC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&(ptr)), (bytes)))
+  AIC_ALLOC(m->proj0_t, static_cast<size_t>(4) * Ds * H * 2);
+  AIC_ALLOC(m->proj1_t, static_cast<size_t>(4) * Ds * Ds * 2);
+  AIC_ALLOC(m->head_t, static_cast<size_t>(m->head_rowtiles) * 16 * Ds * 2);
+  AIC_ALLOC(m->x0, static_cast<size_t>(mpad) * Kmax * 2);
+  AIC_ALLOC(m->h_bf16, static_cast<size_t>(mpad) * Kmax * 2);
+  AIC_ALLOC(m->h_fp8, static_cast<size_t>(mpad) * Ds);
+  AIC_ALLOC(m->cell, static_cast<size_t>(mpad) * Ds * 2);
+  AIC_ALLOC(m->part, static_cast<size_t>(m->gate_splits) * mpad * 4 * Ds * 4);
+  AIC_ALLOC(m->best_val, static_cast<size_t>(m->head_blocks) * mpad * 4);
+  AIC_ALLOC(m->best_idx, static_cast<size_t>(m->head_blocks) * mpad * 4);
+  AIC_ALLOC(m->tokens, static_cast<size_t>(mpad) * 4);
+  AIC_ALLOC(m->amax, 64 * 4);
+  AIC_ALLOC(m->x_scale, 4);
+  hipLaunchKernelGGL(repack_bf16_kernel, dim3(2048), dim3(256), 0, s, static_cast<const uint16_t*>(w->proj0),
+                     m->proj0_t, 4 * Ds, H, m->gate_rowtiles);
+  hipLaunchKernelGGL(repack_bf16_kernel, dim3(2048), dim3(256), 0, s, static_cast<const uint16_t*>(w->proj1),
+                     m->proj1_t, 4 * Ds, Ds, m->gate_rowtiles);
+  hipLaunchKernelGGL(repack_bf16_kernel, dim3(4096), dim3(256), 0, s, static_cast<const uint16_t*>(w->head), m->head_t,
+                     V, Ds, m->head_rowtiles);
+  int rc = launch_status("repack_bf16_kernel");
+  if (rc != AIC_OK) return rc;
+  if (cfg->head_fp8_max_batch > 0) {
+    AIC_ALLOC(m->head8_t, static_cast<size_t>(m->head_rowtiles) * 16 * Ds);
+    if (w->head_fp8) {
+      // caller-provided e4m3 copy is only used for its scale: quantising from the bf16 head with that
+      // scale is the same arithmetic as the reference's post-load hook (fp8.py:207-223)
+      m->head8_scale = w->head_fp8_scale;
+      AIC_HIP_TRY(hipMemcpy(m->x_scale, &m->head8_scale, 4, hipMemcpyHostToDevice));
+    } else {
+      AIC_HIP_TRY(hipMemset(m->amax, 0, 4));
+      hipLaunchKernelGGL(amax_bf16_kernel, dim3(2048), dim3(256), 0, s, static_cast<const uint16_t*>(w->head),
+                         static_cast<int64_t>(V) * Ds, m->amax);
+      hipLaunchKernelGGL(finish_scale_kernel, dim3(1), dim3(1), 0, s, m->amax, m->x_scale);
+      AIC_HIP_TRY(hipMemcpy(&m->head8_scale, m->x_scale, 4, hipMemcpyDeviceToHost));
+    }
+    hipLaunchKernelGGL(quant_repack_fp8_kernel, dim3(4096), dim3(256), 0, s, static_cast<const uint16_t*>(w->head),
+                       m->head8_t, m->x_scale, V, Ds, m->head_rowtiles);
+    if ((rc = launch_status("quant_repack_fp8_kernel")) != AIC_OK) return rc;
+  }
+#undef AIC_ALLOC
+  AIC_HIP_TRY(hipDeviceSynchronize());
+  *out = m;
+  return AIC_OK;
+}
+
+void aic_lstm_destroy(aic_lstm* m) {
+  if (!m) return;
+  void* bufs[] = {m->proj0_t, m->proj1_t, m->head_t, m->head8_t, m->x0,   m->h_bf16, m->h_fp8,
+                  m->cell,    m->part,    m->best_val, m->best_idx, m->tokens, m->amax, m->x_scale};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  delete m;
+}
+
+int aic_lstm_begin(aic_lstm* m, const void* hidden, const int32_t* hidden_index, int batch, void* stream) {
+  AIC_REQUIRE(m && hidden && batch > 0 && batch <= m->cfg.max_batch, "bad arguments to aic_lstm_begin (batch %d)", batch);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  m->cur_batch = batch;
+  m->cur_mt = pad_mt(batch);
+  hipLaunchKernelGGL(ln0_kernel, dim3(m->cur_mt * 16), dim3(256), 0, s, static_cast<const uint16_t*>(hidden),
+                     hidden_index, batch, m->cfg.input_hidden_dim, m->cur_mt, m->cfg.scale_input, m->x0, m->cell,
+                     m->cfg.inner_dim, m->amax, 64);
+  return launch_status("ln0_kernel");
+}
+
+int aic_lstm_head(aic_lstm* m, int head_index, const int32_t* last_tokens, int batch, int64_t* out_tokens,
+                  float* out_vals, void* stream) {
+  AIC_REQUIRE(m && last_tokens && batch == m->cur_batch && head_index >= 0 && head_index < 64,
+              "bad arguments to aic_lstm_head");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(copy_tokens_kernel, dim3(1), dim3(64), 0, s, last_tokens, m->tokens, batch);
+  int rc = launch_status("copy_tokens_kernel");
+  if (rc != AIC_OK) return rc;
+  return run_head(m, head_index, s, out_tokens, 1, 0, out_vals);
+}
+
+int aic_lstm_propose(aic_lstm* m, const void* hidden, const int32_t* hidden_index, const int32_t* last_tokens,
+                     int batch, int num_predict_tokens, int64_t* out_tokens, float* out_vals, void* stream) {
+  AIC_REQUIRE(m && hidden && last_tokens && out_tokens, "null argument to aic_lstm_propose");
+  AIC_REQUIRE(num_predict_tokens > 0 && num_predict_tokens <= 64, "num_predict_tokens out of range");
+  int rc = aic_lstm_begin(m, hidden, hidden_index, batch, stream);
+  if (rc != AIC_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(copy_tokens_kernel, dim3(1), dim3(64), 0, s, last_tokens, m->tokens, batch);
+  if ((rc = launch_status("copy_tokens_kernel")) != AIC_OK) return rc;
+  for (int h = 0; h < num_predict_tokens; ++h) {
+    rc = run_head(m, h, s, out_tokens, num_predict_tokens, h, out_vals);
+    if (rc != AIC_OK) return rc;
+  }
+  return AIC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,875 @@
+// Suffix-tree candidate matching on MI355X + the host<->HBM mirror of the trees, and the C ABI of
+// aic_st_* / aic_sc_* (include/arctic_hip.h).
+//
+// Reference behaviour: SuffixTree::speculate / _match_pattern / _speculate_path
+// (csrc/suffix_cache/suffix_tree.cc:135-224) and the SuffixCache policy
+// (arctic_inference/common/suffix_cache/suffix_cache.py:151-222).
+//
+// Kernel mapping (CDNA4): the work of one engine step is
+//     queries x {prompt tree, global tree} x suffix starts   (<= 64 x 2 x 64 = 8192 items)
+// and every item is a chain of *dependent* HBM/L2 reads (hash probe -> node record -> edge tokens).
+// It is latency-bound, not bandwidth-bound, so the mapping maximises independent chains in flight:
+// one 64-lane wavefront per item (8192 waves = one full residency of 256 CUs x 32 waves), lanes
+// cooperating only where the data is wide: comparing / emitting up to 64 edge tokens per step.
+// A second one-wave-per-query kernel reduces the per-start candidates with the reference's tie
+// rules (strict >, earlier start wins; prompt tree wins ties against the global tree).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "aic_common.h"
+#include "suffix_host.hpp"
+#include "suffix_layout.h"
+
+namespace aic {
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float unif(float v) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
+// Applies mirror deltas: job j copies n records of rec_words words from the blob to their slots.
+__global__ void __launch_bounds__(256) mirror_apply_kernel(const ApplyJob* __restrict__ jobs,
+                                                           const int32_t* __restrict__ blob) {
+  const ApplyJob job = jobs[blockIdx.y];
+  const int64_t total = static_cast<int64_t>(job.n) * job.rec_words;
+  const int32_t* src = blob + job.src_off;
+  const int32_t* idx = job.idx_off >= 0 ? blob + job.idx_off : nullptr;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total;
+       t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t r = t / job.rec_words;
+    const int32_t w = static_cast<int32_t>(t - r * job.rec_words);
+    const int64_t d = idx ? static_cast<int64_t>(idx[r]) : (static_cast<int64_t>(job.dst_first) + r);
+    job.dst[d * job.rec_words + w] = src[t];
+  }
+}
+
+__device__ __forceinline__ int32_t lookup_child(const TreeDesc& T, int32_t parent, int32_t token) {
+  uint32_t h = edge_hash(parent, token) & T.hash_mask;
+  // load factor <= 1/2: ~1.5 probes on average; every lane probes the same slot (one 16-B request)
+  for (uint32_t guard = 0; guard <= T.hash_mask; ++guard) {
+    const int4 s = *reinterpret_cast<const int4*>(&T.hash[h]);
+    const int32_t state = uni(s.w);
+    if (state == SLOT_EMPTY) return -1;
+    if (state == SLOT_FULL && uni(s.x) == parent && uni(s.y) == token) return uni(s.z);
+    h = (h + 1) & T.hash_mask;
+  }
+  return -1;
+}
+
+// One wavefront per (query, tree, suffix start).
+__global__ void __launch_bounds__(256)
+suffix_match_kernel(const QueryRec* __restrict__ queries, const TreeDesc* __restrict__ trees,
+                    const int32_t* __restrict__ patterns, int n_starts, int cap, int n_items,
+                    float* __restrict__ scr_score, int32_t* __restrict__ scr_n,
+                    int32_t* __restrict__ scr_tok, float* __restrict__ scr_prob) {
+  const int lane = threadIdx.x & 63;
+  const int item = uni(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  if (item >= n_items) return;
+  const int per_q = 2 * n_starts;
+  const int qi = item / per_q;
+  const int rem = item - qi * per_q;
+  const int tr = rem / n_starts;
+  const int s = rem - tr * n_starts;
+
+  const QueryRec Q = queries[qi];
+  const int tree_idx = uni(tr == 0 ? Q.prompt_tree : Q.global_tree);
+  const int n = uni(Q.pattern_len);
+  float score = 0.0f;
+  int nt = 0;
+
+  if (tree_idx >= 0 && s < n) {
+    const TreeDesc T = trees[tree_idx];
+    const int32_t* pat = patterns + uni(Q.pattern_off);
+
+    // ---- walk the pattern suffix pat[s:] down from the root (_match_pattern, :167-188) ----------
+    int32_t node = 0, idx = 0, node_len = 0, node_count = 0, node_best = -1;
+    int64_t label = 0;  // offset of the current edge's first token in T.tokens
+    bool ok = true;
+    int i = s;
+    while (i < n) {
+      if (idx >= node_len) {
+        const int32_t child = lookup_child(T, node, uni(pat[i]));
+        if (child < 0) {
+          ok = false;
+          break;
+        }
+        node = child;
+        const int4 a = *reinterpret_cast<const int4*>(&T.nodes[node]);                // count,parent,seq_slot,start
+        const int4 b = *(reinterpret_cast<const int4*>(&T.nodes[node]) + 1);          // length,best,alive,pad
+        node_count = uni(a.x);
+        node_len = uni(b.x);
+        node_best = uni(b.y);
+        label = static_cast<int64_t>(uni(T.seq_base[uni(a.z)])) + uni(a.w);
+        idx = 0;
+      }
+      // compare the rest of this edge with the pattern, 64 tokens per step across the lanes
+      const int m = min(node_len - idx, n - i);
+      bool same = true;
+      for (int j = lane; j < m; j += 64) same &= (T.tokens[label + idx + j] == pat[i + j]);
+      if (!__all(same)) {
+        ok = false;
+        break;
+      }
+      idx += m;
+      i += m;
+    }
+
+    if (ok) {
+      // ---- budget (:149-152): float multiply-add without contraction, double +1e-6, truncate ----
+      const int match_len = n - s;
+      const float scaled = __fadd_rn(__fmul_rn(static_cast<float>(match_len), Q.factor), Q.offset);
+      int budget = static_cast<int>(static_cast<double>(scaled) + 1e-6);
+      budget = max(min(budget, Q.max_spec), 0);
+      budget = min(budget, cap);
+      const float min_prob = Q.min_prob;
+
+      // ---- follow the most frequent continuation (_speculate_path, :190-224) --------------------
+      float prob = 1.0f;
+      const int64_t out = static_cast<int64_t>(item) * cap;
+      while (nt < budget && prob >= min_prob) {
+        if (idx < node_len) {
+          const int m = min(node_len - idx, budget - nt);
+          for (int j = lane; j < m; j += 64) {
+            scr_tok[out + nt + j] = T.tokens[label + idx + j];
+            scr_prob[out + nt + j] = prob;
+          }
+          for (int j = 0; j < m; ++j) score = __fadd_rn(score, prob);  // same order of f32 adds
+          nt += m;
+          idx += m;
+        } else {
+          if (node_best < 0) break;
+          const int32_t parent_count = node_count;
+          node = node_best;
+          const int4 a = *reinterpret_cast<const int4*>(&T.nodes[node]);
+          const int4 b = *(reinterpret_cast<const int4*>(&T.nodes[node]) + 1);
+          node_count = uni(a.x);
+          node_len = uni(b.x);
+          node_best = uni(b.y);
+          label = static_cast<int64_t>(uni(T.seq_base[uni(a.z)])) + uni(a.w);
+          idx = 0;
+          prob = __fmul_rn(prob, __fdiv_rn(static_cast<float>(node_count), static_cast<float>(parent_count)));
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+    scr_score[item] = score;
+    scr_n[item] = nt;
+  }
+}
+
+// One wavefront per query: reduce the per-start candidates of both trees and emit the winner.
+__global__ void __launch_bounds__(64)
+suffix_select_kernel(const QueryRec* __restrict__ queries, int n_starts, int cap,
+                     const float* __restrict__ scr_score, const int32_t* __restrict__ scr_n,
+                     const int32_t* __restrict__ scr_tok, const float* __restrict__ scr_prob,
+                     int32_t* __restrict__ out_n, float* __restrict__ out_score,
+                     int32_t* __restrict__ out_match, int32_t* __restrict__ out_tok,
+                     float* __restrict__ out_prob) {
+  const int qi = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int n = queries[qi].pattern_len;
+  float win_score = 0.0f;
+  int win_item = -1, win_s = 0;
+  for (int tr = 0; tr < 2; ++tr) {
+    const int base = (qi * 2 + tr) * n_starts;
+    float my = 0.0f;
+    int my_s = 0x7fffffff;
+    for (int s = lane; s < n_starts; s += 64) {
+      const float v = scr_score[base + s];
+      if (v > my) {  // strict: the earliest start (longest match) of equal scores stays
+        my = v;
+        my_s = s;
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      const float o = __shfl_xor(my, off);
+      const int os = __shfl_xor(my_s, off);
+      if (o > my || (o == my && os < my_s)) {
+        my = o;
+        my_s = os;
+      }
+    }
+    // prompt tree first; the global tree replaces it only with a strictly higher score
+    if (my > win_score) {
+      win_score = my;
+      win_item = base + my_s;
+      win_s = my_s;
+    }
+  }
+  int cnt = 0;
+  if (win_item >= 0) {
+    cnt = scr_n[win_item];
+    for (int j = lane; j < cnt; j += 64) {
+      out_tok[static_cast<int64_t>(qi) * cap + j] = scr_tok[static_cast<int64_t>(win_item) * cap + j];
+      out_prob[static_cast<int64_t>(qi) * cap + j] = scr_prob[static_cast<int64_t>(win_item) * cap + j];
+    }
+  }
+  if (lane == 0) {
+    out_n[qi] = cnt;
+    out_score[qi] = win_score;
+    out_match[qi] = win_item >= 0 ? n - win_s : 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// device memory: power-of-two size classes, cached (prompt trees come and go every request)
+// ------------------------------------------------------------------------------------------------
+class DevPool {
+ public:
+  ~DevPool() {
+    for (auto& kv : free_)
+      for (void* p : kv.second) (void)hipFree(p);
+  }
+  static size_t round(size_t bytes) {
+    size_t c = 1 << 16;
+    while (c < bytes) c <<= 1;
+    return c;
+  }
+  int get(size_t bytes, void** out) {
+    const size_t c = round(bytes);
+    auto& fl = free_[c];
+    if (!fl.empty()) {
+      *out = fl.back();
+      fl.pop_back();
+      return AIC_OK;
+    }
+    AIC_HIP_TRY(hipMalloc(out, c));
+    return AIC_OK;
+  }
+  void put(void* p, size_t bytes) {
+    if (p) free_[round(bytes)].push_back(p);
+  }
+
+ private:
+  std::unordered_map<size_t, std::vector<void*>> free_;
+};
+
+struct TreeImage {
+  NodeRec* nodes = nullptr;
+  size_t nodes_cap = 0;  // records
+  HashSlot* hash = nullptr;
+  size_t hash_cap = 0;
+  int32_t* tokens = nullptr;
+  size_t tokens_cap = 0;
+  int32_t* seq_base = nullptr;
+  size_t seq_cap = 0;
+  size_t seq_synced = 0;  // seq_base entries already mirrored
+};
+
+class Mirror;
+
+}  // namespace aic
+
+struct aic_suffix_tree {
+  explicit aic_suffix_tree(int depth) : host(depth) {}
+  aic::HostTree host;
+  aic::TreeImage img;
+  aic::DevPool* pool = nullptr;           // who owns img's buffers
+  std::unique_ptr<aic::Mirror> own;       // standalone trees mirror themselves
+  std::unique_ptr<aic::DevPool> own_pool;
+};
+
+namespace aic {
+
+// Collects the deltas of any number of trees (+ the query data) into one pinned blob, ships it with
+// one H2D copy and applies it with one kernel launch.
+class Mirror {
+ public:
+  ~Mirror() {
+    if (pinned_) (void)hipHostFree(pinned_);
+    if (dblob_) (void)hipFree(dblob_);
+    if (dscr_) (void)hipFree(dscr_);
+    if (pin_out_) (void)hipHostFree(pin_out_);
+    if (ev0_) (void)hipEventDestroy(ev0_);
+    if (ev1_) (void)hipEventDestroy(ev1_);
+  }
+
+  void begin() {
+    words_ = 0;
+    jobs_.clear();
+    descs_.clear();
+    max_job_words_ = 0;
+  }
+
+  // reserves `n` int32 words (16-byte aligned start) in the pinned blob, returns the word offset
+  int reserve(size_t n, int64_t* off) {
+    words_ = (words_ + 3) & ~static_cast<size_t>(3);
+    const size_t need = (words_ + n + 64) * 4;
+    if (need > pinned_cap_) {
+      size_t cap = pinned_cap_ ? pinned_cap_ : (1 << 20);
+      while (cap < need) cap *= 2;
+      void* np = nullptr;
+      AIC_HIP_TRY(hipHostMalloc(&np, cap, hipHostMallocDefault));
+      if (pinned_) {
+        std::memcpy(np, pinned_, words_ * 4);
+        (void)hipHostFree(pinned_);
+      }
+      pinned_ = static_cast<int32_t*>(np);
+      pinned_cap_ = cap;
+    }
+    *off = static_cast<int64_t>(words_);
+    words_ += n;
+    return AIC_OK;
+  }
+  int32_t* at(int64_t off) { return pinned_ + off; }
+
+  int add_job(void* dst, int64_t src_off, int64_t idx_off, int32_t dst_first, int32_t n, int32_t rec_words) {
+    if (n <= 0) return AIC_OK;
+    ApplyJob j;
+    j.dst = static_cast<int32_t*>(dst);
+    j.src_off = src_off;
+    j.idx_off = idx_off;
+    j.dst_first = dst_first;
+    j.n = n;
+    j.rec_words = rec_words;
+    j.pad = 0;
+    jobs_.push_back(j);
+    max_job_words_ = std::max<int64_t>(max_job_words_, static_cast<int64_t>(n) * rec_words);
+    return AIC_OK;
+  }
+
+  template <typename T>
+  int grow(DevPool& pool, T** buf, size_t* cap, size_t need, bool* moved) {
+    *moved = false;
+    if (need <= *cap && *buf) return AIC_OK;
+    size_t c = *cap ? *cap : 1024;
+    while (c < need) c *= 2;
+    void* np = nullptr;
+    int rc = pool.get(c * sizeof(T), &np);
+    if (rc != AIC_OK) return rc;
+    // round the capacity up to what the pool really handed out
+    c = DevPool::round(c * sizeof(T)) / sizeof(T);
+    if (*buf) pool.put(*buf, *cap * sizeof(T));
+    *buf = static_cast<T*>(np);
+    *cap = c;
+    *moved = true;
+    return AIC_OK;
+  }
+
+  // Queues everything tree `t` changed since its last mirror; returns its TreeDesc index.
+  int add_tree(aic_suffix_tree* t, DevPool& pool, int* desc_index) {
+    HostTree& H = t->host;
+    TreeImage& I = t->img;
+    t->pool = &pool;
+    bool moved = false;
+    int rc;
+    int64_t off, ioff;
+
+    // nodes
+    const size_t n_nodes = H.recs().size();
+    if ((rc = grow(pool, &I.nodes, &I.nodes_cap, n_nodes, &moved)) != AIC_OK) return rc;
+    if (moved) {
+      if ((rc = reserve(n_nodes * 8, &off)) != AIC_OK) return rc;
+      std::memcpy(at(off), H.recs().data(), n_nodes * sizeof(NodeRec));
+      add_job(I.nodes, off, -1, 0, static_cast<int32_t>(n_nodes), 8);
+    } else if (!H.dirty_nodes().empty()) {
+      const size_t d = H.dirty_nodes().size();
+      if ((rc = reserve(d * 8, &off)) != AIC_OK) return rc;
+      if ((rc = reserve(d, &ioff)) != AIC_OK) return rc;
+      int32_t* rec = at(off);
+      int32_t* idx = at(ioff);
+      for (size_t k = 0; k < d; ++k) {
+        const int32_t ni = H.dirty_nodes()[k];
+        std::memcpy(rec + k * 8, &H.recs()[ni], sizeof(NodeRec));
+        idx[k] = ni;
+      }
+      add_job(I.nodes, off, ioff, 0, static_cast<int32_t>(d), 8);
+    }
+
+    // hash table
+    const size_t n_slots = H.slots().size();
+    if ((rc = grow(pool, &I.hash, &I.hash_cap, n_slots, &moved)) != AIC_OK) return rc;
+    if (moved || H.hash_rebuilt()) {
+      if ((rc = reserve(n_slots * 4, &off)) != AIC_OK) return rc;
+      std::memcpy(at(off), H.slots().data(), n_slots * sizeof(HashSlot));
+      add_job(I.hash, off, -1, 0, static_cast<int32_t>(n_slots), 4);
+    } else if (!H.dirty_slots().empty()) {
+      const size_t d = H.dirty_slots().size();
+      if ((rc = reserve(d * 4, &off)) != AIC_OK) return rc;
+      if ((rc = reserve(d, &ioff)) != AIC_OK) return rc;
+      int32_t* rec = at(off);
+      int32_t* idx = at(ioff);
+      for (size_t k = 0; k < d; ++k) {
+        const int32_t si = H.dirty_slots()[k];
+        std::memcpy(rec + k * 4, &H.slots()[si], sizeof(HashSlot));
+        idx[k] = si;
+      }
+      add_job(I.hash, off, ioff, 0, static_cast<int32_t>(d), 4);
+    }
+
+    // token regions: make every sequence fit, then upload what is new
+    auto& seqs = H.seqs();
+    bool any_moved = false;
+    for (auto& s : seqs) any_moved |= H.fit_region(s, static_cast<int32_t>(s.toks.size()));
+    if ((rc = grow(pool, &I.tokens, &I.tokens_cap, static_cast<size_t>(H.pool_end()), &moved)) != AIC_OK) return rc;
+    if (moved)
+      for (auto& s : seqs) s.synced = 0;
+    for (auto& s : seqs) {
+      const int32_t have = static_cast<int32_t>(s.toks.size());
+      if (have > s.synced) {
+        const int32_t cnt = have - s.synced;
+        if ((rc = reserve(cnt, &off)) != AIC_OK) return rc;
+        std::memcpy(at(off), s.toks.data() + s.synced, static_cast<size_t>(cnt) * 4);
+        add_job(I.tokens, off, -1, s.base + s.synced, cnt, 1);
+        s.synced = have;
+      }
+    }
+    // seq_base table
+    if ((rc = grow(pool, &I.seq_base, &I.seq_cap, std::max<size_t>(seqs.size(), 1), &moved)) != AIC_OK) return rc;
+    if (moved || any_moved || I.seq_synced != seqs.size()) {
+      if ((rc = reserve(std::max<size_t>(seqs.size(), 1), &off)) != AIC_OK) return rc;
+      for (size_t k = 0; k < seqs.size(); ++k) at(off)[k] = seqs[k].base;
+      add_job(I.seq_base, off, -1, 0, static_cast<int32_t>(seqs.size()), 1);
+      I.seq_synced = seqs.size();
+    }
+    H.clear_dirty();
+
+    TreeDesc d;
+    d.nodes = I.nodes;
+    d.hash = I.hash;
+    d.tokens = I.tokens;
+    d.seq_base = I.seq_base;
+    d.hash_mask = H.hash_mask();
+    d.n_nodes = static_cast<int32_t>(n_nodes);
+    d.pad0 = d.pad1 = 0;
+    *desc_index = static_cast<int>(descs_.size());
+    descs_.push_back(d);
+    return AIC_OK;
+  }
+
+  // Runs the batch: blob H2D, delta apply, match + select, results D2H, stream sync.
+  int run(const std::vector<QueryRec>& queries, const std::vector<int32_t>& pattern_pool, int n_starts, int cap,
+          int32_t* out_tokens, float* out_probs, int32_t* out_n, float* out_score, int32_t* out_match,
+          hipStream_t stream) {
+    const int nq = static_cast<int>(queries.size());
+    int rc;
+    int64_t q_off, p_off, d_off, j_off;
+    // fix pattern offsets relative to the blob once the pool position is known
+    if ((rc = reserve(pattern_pool.size() + 1, &p_off)) != AIC_OK) return rc;
+    std::memcpy(at(p_off), pattern_pool.data(), pattern_pool.size() * 4);
+    if ((rc = reserve(static_cast<size_t>(nq) * 8, &q_off)) != AIC_OK) return rc;
+    std::memcpy(at(q_off), queries.data(), static_cast<size_t>(nq) * sizeof(QueryRec));
+    const size_t desc_words = descs_.size() * sizeof(TreeDesc) / 4;
+    if ((rc = reserve(desc_words + 4, &d_off)) != AIC_OK) return rc;
+    std::memcpy(at(d_off), descs_.data(), descs_.size() * sizeof(TreeDesc));
+    const size_t job_words = jobs_.size() * sizeof(ApplyJob) / 4;
+    if ((rc = reserve(job_words + 4, &j_off)) != AIC_OK) return rc;
+    std::memcpy(at(j_off), jobs_.data(), jobs_.size() * sizeof(ApplyJob));
+
+    const size_t blob_bytes = words_ * 4;
+    if (blob_bytes > dblob_cap_) {
+      if (dblob_) AIC_HIP_TRY(hipFree(dblob_));
+      dblob_cap_ = std::max<size_t>(blob_bytes * 2, 1 << 20);
+      AIC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dblob_), dblob_cap_));
+    }
+    // scratch: per item {score, n} + cap tokens + cap probs; outputs per query
+    const size_t n_items = static_cast<size_t>(nq) * 2 * n_starts;
+    const size_t scr_words = n_items * 2 + n_items * cap * 2;
+    const size_t out_words = static_cast<size_t>(nq) * (3 + 2 * static_cast<size_t>(cap));
+    const size_t scr_bytes = (scr_words + out_words + 16) * 4;
+    if (scr_bytes > dscr_cap_) {
+      if (dscr_) AIC_HIP_TRY(hipFree(dscr_));
+      dscr_cap_ = scr_bytes * 2;
+      AIC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dscr_), dscr_cap_));
+    }
+    if (out_words * 4 > pin_out_cap_) {
+      if (pin_out_) AIC_HIP_TRY(hipHostFree(pin_out_));
+      pin_out_cap_ = out_words * 8;
+      AIC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pin_out_), pin_out_cap_, hipHostMallocDefault));
+    }
+    if (!ev0_) {
+      AIC_HIP_TRY(hipEventCreate(&ev0_));
+      AIC_HIP_TRY(hipEventCreate(&ev1_));
+    }
+
+    AIC_HIP_TRY(hipMemcpyAsync(dblob_, pinned_, blob_bytes, hipMemcpyHostToDevice, stream));
+    mirrored_bytes_ = static_cast<int64_t>(blob_bytes);
+    if (!jobs_.empty()) {
+      const int bx = static_cast<int>(std::min<int64_t>(std::max<int64_t>(max_job_words_ / 1024, 1), 256));
+      dim3 grid(bx, static_cast<unsigned>(jobs_.size()));
+      hipLaunchKernelGGL(mirror_apply_kernel, grid, dim3(256), 0, stream,
+                         reinterpret_cast<const ApplyJob*>(dblob_ + j_off), dblob_);
+      if ((rc = launch_status("mirror_apply_kernel")) != AIC_OK) return rc;
+    }
+    float* scr_score = reinterpret_cast<float*>(dscr_);
+    int32_t* scr_n = dscr_ + n_items;
+    int32_t* scr_tok = dscr_ + 2 * n_items;
+    float* scr_prob = reinterpret_cast<float*>(dscr_ + 2 * n_items + n_items * cap);
+    int32_t* d_out = dscr_ + scr_words;
+    int32_t* o_n = d_out;
+    float* o_score = reinterpret_cast<float*>(d_out + nq);
+    int32_t* o_match = d_out + 2 * nq;
+    int32_t* o_tok = d_out + 3 * nq;
+    float* o_prob = reinterpret_cast<float*>(d_out + 3 * nq + static_cast<size_t>(nq) * cap);
+
+    AIC_HIP_TRY(hipEventRecord(ev0_, stream));
+    const int waves_per_block = 4;
+    const int blocks = static_cast<int>((n_items + waves_per_block - 1) / waves_per_block);
+    hipLaunchKernelGGL(suffix_match_kernel, dim3(blocks), dim3(64 * waves_per_block), 0, stream,
+                       reinterpret_cast<const QueryRec*>(dblob_ + q_off),
+                       reinterpret_cast<const TreeDesc*>(dblob_ + d_off), dblob_ + p_off, n_starts, cap,
+                       static_cast<int>(n_items), scr_score, scr_n, scr_tok, scr_prob);
+    if ((rc = launch_status("suffix_match_kernel")) != AIC_OK) return rc;
+    hipLaunchKernelGGL(suffix_select_kernel, dim3(nq), dim3(64), 0, stream,
+                       reinterpret_cast<const QueryRec*>(dblob_ + q_off), n_starts, cap, scr_score, scr_n,
+                       scr_tok, scr_prob, o_n, o_score, o_match, o_tok, o_prob);
+    if ((rc = launch_status("suffix_select_kernel")) != AIC_OK) return rc;
+    AIC_HIP_TRY(hipEventRecord(ev1_, stream));
+    AIC_HIP_TRY(hipMemcpyAsync(pin_out_, d_out, out_words * 4, hipMemcpyDeviceToHost, stream));
+    AIC_HIP_TRY(hipStreamSynchronize(stream));
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) match_us_ = ms * 1000.0f;
+
+    const int32_t* h_n = pin_out_;
+    const float* h_score = reinterpret_cast<const float*>(pin_out_ + nq);
+    const int32_t* h_match = pin_out_ + 2 * nq;
+    const int32_t* h_tok = pin_out_ + 3 * nq;
+    const float* h_prob = reinterpret_cast<const float*>(pin_out_ + 3 * nq + static_cast<size_t>(nq) * cap);
+    for (int i = 0; i < nq; ++i) {
+      out_n[i] = h_n[i];
+      out_score[i] = h_score[i];
+      out_match[i] = h_match[i];
+      std::memcpy(out_tokens + static_cast<size_t>(i) * cap, h_tok + static_cast<size_t>(i) * cap,
+                  static_cast<size_t>(h_n[i]) * 4);
+      std::memcpy(out_probs + static_cast<size_t>(i) * cap, h_prob + static_cast<size_t>(i) * cap,
+                  static_cast<size_t>(h_n[i]) * 4);
+    }
+    return AIC_OK;
+  }
+
+  float match_us() const { return match_us_; }
+  int64_t mirrored_bytes() const { return mirrored_bytes_; }
+
+ private:
+  int32_t* pinned_ = nullptr;
+  size_t pinned_cap_ = 0;
+  size_t words_ = 0;
+  std::vector<ApplyJob> jobs_;
+  std::vector<TreeDesc> descs_;
+  int64_t max_job_words_ = 0;
+  int32_t* dblob_ = nullptr;
+  size_t dblob_cap_ = 0;
+  int32_t* dscr_ = nullptr;
+  size_t dscr_cap_ = 0;
+  int32_t* pin_out_ = nullptr;
+  size_t pin_out_cap_ = 0;
+  hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+  float match_us_ = 0.0f;
+  int64_t mirrored_bytes_ = 0;
+};
+
+static void release_image(aic_suffix_tree* t) {
+  if (!t->pool) return;
+  TreeImage& I = t->img;
+  t->pool->put(I.nodes, I.nodes_cap * sizeof(NodeRec));
+  t->pool->put(I.hash, I.hash_cap * sizeof(HashSlot));
+  t->pool->put(I.tokens, I.tokens_cap * sizeof(int32_t));
+  t->pool->put(I.seq_base, I.seq_cap * sizeof(int32_t));
+  I = TreeImage();
+}
+
+}  // namespace aic
+
+struct aic_suffix_cache {
+  explicit aic_suffix_cache(int depth) : max_depth(depth), global(new aic_suffix_tree(depth)) {}
+  ~aic_suffix_cache() {
+    // trees hand their buffers back to `pool` before the pool frees them
+    for (auto& kv : prompts) aic::release_image(kv.second.get());
+    aic::release_image(global.get());
+  }
+  int max_depth;
+  aic::DevPool pool;
+  aic::Mirror mirror;
+  std::unique_ptr<aic_suffix_tree> global;
+  std::unordered_map<int64_t, std::unique_ptr<aic_suffix_tree>> prompts;
+  std::unordered_map<int64_t, int32_t> seq_of;
+};
+
+using namespace aic;
+
+extern "C" {
+
+// ---- tree-level API (pybind.cc:24-38) -----------------------------------------------------------
+aic_suffix_tree* aic_st_create(int max_depth) {
+  if (max_depth <= 0) {
+    set_error("max_depth must be positive");
+    return nullptr;
+  }
+  return new aic_suffix_tree(max_depth);
+}
+void aic_st_destroy(aic_suffix_tree* t) {
+  if (!t) return;
+  if (t->own_pool) release_image(t);
+  delete t;
+}
+int aic_st_num_seqs(const aic_suffix_tree* t) { return t ? t->host.num_seqs() : AIC_ERR_INVALID; }
+int aic_st_append(aic_suffix_tree* t, int seq_id, int token) {
+  AIC_REQUIRE(t, "null tree");
+  t->host.append(seq_id, token);
+  return AIC_OK;
+}
+int aic_st_extend(aic_suffix_tree* t, int seq_id, const int32_t* tokens, int n) {
+  AIC_REQUIRE(t && (tokens || n == 0) && n >= 0, "bad arguments to aic_st_extend");
+  for (int i = 0; i < n; ++i) t->host.append(seq_id, tokens[i]);
+  return AIC_OK;
+}
+
+int aic_st_speculate(aic_suffix_tree* t, const int32_t* pattern, int n, int max_spec_tokens, float factor,
+                     float offset, float min_prob, int use_tree_spec, int32_t* out_tokens, int32_t* out_parents,
+                     float* out_probs, int cap, float* out_score, int32_t* out_match_len, void* stream) {
+  AIC_REQUIRE(t && pattern && n > 0 && cap >= 0 && out_score && out_match_len, "bad arguments to aic_st_speculate");
+  const int depth = t->host.max_depth();
+  if (n > depth) {  // only the last max_depth tokens can match (suffix_tree.cc:142)
+    pattern += n - depth;
+    n = depth;
+  }
+  if (use_tree_spec) {
+    HostCandidate c = t->host.speculate_tree(pattern, n, max_spec_tokens, factor, offset, min_prob);
+    const int m = std::min<int>(static_cast<int>(c.token_ids.size()), cap);
+    for (int i = 0; i < m; ++i) {
+      out_tokens[i] = c.token_ids[i];
+      if (out_parents) out_parents[i] = c.parents[i];
+      out_probs[i] = c.probs[i];
+    }
+    *out_score = c.score;
+    *out_match_len = c.match_len;
+    return m;
+  }
+  AIC_NEED_DEVICE();
+  if (!t->own) {
+    t->own.reset(new Mirror());
+    t->own_pool.reset(new DevPool());
+  }
+  DevPool& pool = t->pool ? *t->pool : *t->own_pool;
+  Mirror& mir = *t->own;
+  mir.begin();
+  int di = -1;
+  int rc = mir.add_tree(t, pool, &di);
+  if (rc != AIC_OK) return rc;
+  QueryRec q;
+  q.pattern_off = 0;
+  q.pattern_len = n;
+  q.max_spec = max_spec_tokens;
+  q.prompt_tree = -1;
+  q.global_tree = di;
+  q.factor = factor;
+  q.offset = offset;
+  q.min_prob = min_prob;
+  std::vector<QueryRec> qs(1, q);
+  std::vector<int32_t> pool_words(pattern, pattern + n);
+  const int kcap = std::max(std::min(std::max(max_spec_tokens, 0), depth), 1);
+  std::vector<int32_t> toks(kcap);
+  std::vector<float> probs(kcap);
+  int32_t cnt = 0, mlen = 0;
+  float score = 0.0f;
+  rc = mir.run(qs, pool_words, n, kcap, toks.data(), probs.data(), &cnt, &score, &mlen,
+               static_cast<hipStream_t>(stream));
+  if (rc != AIC_OK) return rc;
+  const int m = std::min<int>(cnt, cap);
+  for (int i = 0; i < m; ++i) {
+    out_tokens[i] = toks[i];
+    if (out_parents) out_parents[i] = i - 1;
+    out_probs[i] = probs[i];
+  }
+  *out_score = score;
+  *out_match_len = mlen;
+  return m;
+}
+
+int aic_st_export(aic_suffix_tree* t, int32_t* n_nodes, int32_t* n_slots, int32_t* n_tokens, int32_t* n_seq_slots,
+                  int32_t* nodes, int32_t* hash, int32_t* tokens, int32_t* seq_base, int32_t* seq_ids) {
+  AIC_REQUIRE(t && n_nodes && n_slots && n_tokens && n_seq_slots, "bad arguments to aic_st_export");
+  HostTree& H = t->host;
+  for (auto& s : H.seqs()) H.fit_region(s, static_cast<int32_t>(s.toks.size()));
+  *n_nodes = static_cast<int32_t>(H.recs().size());
+  *n_slots = static_cast<int32_t>(H.slots().size());
+  *n_tokens = H.pool_end();
+  *n_seq_slots = static_cast<int32_t>(H.seqs().size());
+  if (nodes) std::memcpy(nodes, H.recs().data(), H.recs().size() * sizeof(NodeRec));
+  if (hash) std::memcpy(hash, H.slots().data(), H.slots().size() * sizeof(HashSlot));
+  if (tokens) {
+    std::memset(tokens, 0xff, static_cast<size_t>(H.pool_end()) * 4);
+    for (const auto& s : H.seqs()) std::memcpy(tokens + s.base, s.toks.data(), s.toks.size() * 4);
+  }
+  for (size_t k = 0; k < H.seqs().size(); ++k) {
+    if (seq_base) seq_base[k] = H.seqs()[k].base;
+    if (seq_ids) seq_ids[k] = H.seqs()[k].id;
+  }
+  return AIC_OK;
+}
+
+int aic_st_selfcheck(aic_suffix_tree* t) {
+  AIC_REQUIRE(t, "null tree");
+  return t->host.selfcheck();
+}
+
+// ---- cache-level API (suffix_cache.py:57-222) ---------------------------------------------------
+aic_suffix_cache* aic_sc_create(int max_depth) {
+  if (max_depth <= 0) {
+    set_error("max_depth must be positive");
+    return nullptr;
+  }
+  return new aic_suffix_cache(max_depth);
+}
+void aic_sc_destroy(aic_suffix_cache* c) { delete c; }
+int aic_sc_has_prompt(const aic_suffix_cache* c, int64_t req) {
+  return c && c->prompts.count(req) ? 1 : 0;
+}
+int aic_sc_cache_prompt(aic_suffix_cache* c, int64_t req, const int32_t* tokens, int n) {
+  AIC_REQUIRE(c && (tokens || n == 0) && n >= 0, "bad arguments to aic_sc_cache_prompt");
+  if (c->prompts.count(req)) {
+    set_error("prompt already exists for request %lld", static_cast<long long>(req));
+    return AIC_ERR_EXISTS;
+  }
+  std::unique_ptr<aic_suffix_tree> t(new aic_suffix_tree(c->max_depth));
+  for (int i = 0; i < n; ++i) t->host.append(0, tokens[i]);
+  c->prompts.emplace(req, std::move(t));
+  return AIC_OK;
+}
+int aic_sc_cache_prompts(aic_suffix_cache* c, int n_req, const int64_t* reqs, const int32_t* tokens,
+                         const int32_t* lens, int n_threads) {
+  AIC_REQUIRE(c && reqs && lens && n_req >= 0, "bad arguments to aic_sc_cache_prompts");
+  std::vector<int64_t> offs(n_req + 1, 0);
+  for (int i = 0; i < n_req; ++i) {
+    AIC_REQUIRE(lens[i] >= 0, "negative prompt length");
+    if (c->prompts.count(reqs[i])) {
+      set_error("prompt already exists for request %lld", static_cast<long long>(reqs[i]));
+      return AIC_ERR_EXISTS;
+    }
+    for (int j = 0; j < i; ++j) AIC_REQUIRE(reqs[j] != reqs[i], "duplicate request in batch");
+    offs[i + 1] = offs[i] + lens[i];
+  }
+  std::vector<std::unique_ptr<aic_suffix_tree>> built(n_req);
+  for (int i = 0; i < n_req; ++i) built[i].reset(new aic_suffix_tree(c->max_depth));
+  // prompt trees are independent: build them on host threads
+  const int nt = std::max(1, std::min(n_threads, n_req));
+  auto work = [&](int tid) {
+    for (int i = tid; i < n_req; i += nt)
+      for (int j = 0; j < lens[i]; ++j) built[i]->host.append(0, tokens[offs[i] + j]);
+  };
+  if (nt == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int k = 0; k < nt; ++k) th.emplace_back(work, k);
+    for (auto& x : th) x.join();
+  }
+  for (int i = 0; i < n_req; ++i) c->prompts.emplace(reqs[i], std::move(built[i]));
+  return AIC_OK;
+}
+int aic_sc_evict_prompt(aic_suffix_cache* c, int64_t req) {
+  AIC_REQUIRE(c, "null cache");
+  auto it = c->prompts.find(req);
+  if (it == c->prompts.end()) {
+    set_error("prompt does not exist for request %lld", static_cast<long long>(req));
+    return AIC_ERR_NOT_FOUND;
+  }
+  release_image(it->second.get());
+  c->prompts.erase(it);
+  return AIC_OK;
+}
+int aic_sc_update_response(aic_suffix_cache* c, int64_t req, const int32_t* tokens, int n) {
+  AIC_REQUIRE(c && (tokens || n == 0) && n >= 0, "bad arguments to aic_sc_update_response");
+  auto it = c->seq_of.find(req);
+  if (it == c->seq_of.end()) it = c->seq_of.emplace(req, static_cast<int32_t>(c->seq_of.size())).first;
+  const int32_t sid = it->second;
+  for (int i = 0; i < n; ++i) c->global->host.append(sid, tokens[i]);
+  auto pt = c->prompts.find(req);
+  if (pt != c->prompts.end())
+    for (int i = 0; i < n; ++i) pt->second->host.append(0, tokens[i]);
+  return AIC_OK;
+}
+
+int aic_sc_speculate_batch(aic_suffix_cache* c, int n_query, const int64_t* reqs, const int32_t* patterns,
+                           const int32_t* pattern_lens, const int32_t* max_spec_tokens, const float* factor,
+                           const float* offset, const float* min_prob, const int32_t* use_prompt, int cap,
+                           int32_t* out_tokens, float* out_probs, int32_t* out_n, float* out_score,
+                           int32_t* out_match_len, void* stream) {
+  AIC_REQUIRE(c && n_query >= 0 && cap > 0, "bad arguments to aic_sc_speculate_batch");
+  if (n_query == 0) return AIC_OK;
+  AIC_REQUIRE(reqs && patterns && pattern_lens && max_spec_tokens && factor && offset && min_prob && use_prompt &&
+                  out_tokens && out_probs && out_n && out_score && out_match_len,
+              "null array passed to aic_sc_speculate_batch");
+  // validate before touching the device (suffix_cache.py:189-192)
+  for (int i = 0; i < n_query; ++i) {
+    if (pattern_lens[i] <= 0) {
+      set_error("pattern must not be empty (query %d)", i);
+      return AIC_ERR_INVALID;
+    }
+    if (use_prompt[i] && !c->prompts.count(reqs[i])) {
+      set_error("prompt does not exist for request %lld", static_cast<long long>(reqs[i]));
+      return AIC_ERR_NOT_FOUND;
+    }
+  }
+  AIC_NEED_DEVICE();
+  Mirror& mir = c->mirror;
+  mir.begin();
+  int rc, gdesc = -1;
+  if ((rc = mir.add_tree(c->global.get(), c->pool, &gdesc)) != AIC_OK) return rc;
+  std::unordered_map<int64_t, int> pdesc;
+  std::vector<QueryRec> qs(n_query);
+  std::vector<int32_t> pool_words;
+  int64_t src = 0;
+  int n_starts = 1;
+  for (int i = 0; i < n_query; ++i) {
+    int len = pattern_lens[i];
+    const int32_t* p = patterns + src;
+    src += len;
+    if (len > c->max_depth) {  // suffix_cache.py:197-198
+      p += len - c->max_depth;
+      len = c->max_depth;
+    }
+    QueryRec& q = qs[i];
+    q.pattern_off = static_cast<int32_t>(pool_words.size());
+    q.pattern_len = len;
+    pool_words.insert(pool_words.end(), p, p + len);
+    q.max_spec = max_spec_tokens[i];
+    q.factor = factor[i];
+    q.offset = offset[i];
+    q.min_prob = min_prob[i];
+    q.global_tree = gdesc;
+    q.prompt_tree = -1;
+    if (use_prompt[i]) {
+      auto it = pdesc.find(reqs[i]);
+      if (it == pdesc.end()) {
+        int di = -1;
+        if ((rc = mir.add_tree(c->prompts[reqs[i]].get(), c->pool, &di)) != AIC_OK) return rc;
+        it = pdesc.emplace(reqs[i], di).first;
+      }
+      q.prompt_tree = it->second;
+    }
+    n_starts = std::max(n_starts, len);
+  }
+  return mir.run(qs, pool_words, n_starts, cap, out_tokens, out_probs, out_n, out_score, out_match_len,
+                 static_cast<hipStream_t>(stream));
+}
+
+int aic_sc_last_stats(const aic_suffix_cache* c, float* match_us, int64_t* mirrored_bytes, int64_t* n_nodes_total) {
+  AIC_REQUIRE(c, "null cache");
+  if (match_us) *match_us = c->mirror.match_us();
+  if (mirrored_bytes) *mirrored_bytes = c->mirror.mirrored_bytes();
+  if (n_nodes_total) {
+    int64_t n = static_cast<int64_t>(c->global->host.num_nodes());
+    for (const auto& kv : c->prompts) n += static_cast<int64_t>(kv.second->host.num_nodes());
+    *n_nodes_total = n;
+  }
+  return AIC_OK;
+}
+aic_suffix_tree* aic_sc_global_tree(aic_suffix_cache* c) { return c ? c->global.get() : nullptr; }
+aic_suffix_tree* aic_sc_prompt_tree(aic_suffix_cache* c, int64_t req) {
+  if (!c) return nullptr;
+  auto it = c->prompts.find(req);
+  return it == c->prompts.end() ? nullptr : it->second.get();
+}
+
+}  // extern "C"

@@ -1,0 +1,372 @@
+// A5 — multi-token verify attention over a paged KV cache (the dominant kernel of a spec-decode step).
+//
+// Reference path: UlyssesAttentionPatch.forward hands q_/k_/v_ to vLLM's attention backend
+// (/root/reference/arctic_inference/vllm/ulysses.py:510); no attention source exists in the
+// reference.  Semantics (restated in oracle/spec_oracle.py): for request i with
+// q_len_i = 1 + n_draft_i new tokens and context seq_lens[i] (new tokens included, K/V already
+// written), query position j attends keys [0, seq_lens[i] - q_len_i + j]; GQA; FlashAttention page
+// layout [num_blocks, block_size, Hkv, D] (llama_swiftkv.py:617).
+//
+// Roofline: HBM.  Per request and layer the kernel must read S x 2 x Hkv x D x 2 B of KV (16.8 MB
+// at S=4096, Llama-3.1-8B) for 2 x q_len x Hq x D x S flops -> ~32 flop/B at q_len = 4, two orders
+// of magnitude under the MFMA ridge.  So the design goal is bytes in flight, not MFMA utilisation:
+//   * flash-decoding split: grid (request x kv head, splits, row groups) of 4-wave workgroups and
+//     every WAVE owns its own token range with its own online-softmax state -> no workgroup
+//     barrier in the main loop, thousands of independent streams, each with the next 32-token tile
+//     (8 KiB K + 8 KiB V) prefetched into registers while the current one is computed;
+//   * all G x q_len query rows of a kv head ride one MFMA tile (16 rows = 4 positions x G=4), so
+//     the KV bytes are read once for all draft positions;
+//   * S^T = K Q^T ("swapped" product): the accumulator then holds, per lane, 8 tokens of ONE query
+//     row — soft-max statistics are lane-local plus two shuffles, and the same registers are
+//     directly the B operand of O^T = V^T P^T (k-slot permutation shared by both operands), so P
+//     never touches LDS;
+//   * V is loaded row-contiguous (full 256-byte rows), staged in a wave-private LDS tile and read
+//     back transposed with ds_read_b64_tr_b16 as the MFMA A operand.
+// Partials (m, l, unnormalised O) per (split, wave) go to a workspace; a second kernel merges them.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "aic_common.h"
+
+namespace aic {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+constexpr int kTile = 32;  // tokens per inner step
+constexpr int kD = 128;
+
+struct AttnParams {
+  const uint16_t* q;
+  const uint16_t* k_cache;
+  const uint16_t* v_cache;
+  const int32_t* block_table;
+  const int32_t* seq_lens;
+  const int32_t* query_start_loc;
+  float* ws_o;   // [n_parts][T*Hq][D]
+  float* ws_ml;  // [n_parts][T*Hq][2]
+  int64_t q_stride;
+  int64_t block_stride;
+  int max_blocks;
+  int num_q_heads;
+  int num_kv_heads;
+  int block_size;
+  int n_splits;
+  int total_rows;  // T * Hq
+  float sm_scale;
+};
+
+template <int MTQ>
+__global__ void __launch_bounds__(256, 2) verify_attn_kernel(AttnParams P) {
+  __shared__ uint4 v_lds[4][kTile * 16];  // per wave: 32 tokens x 256 B
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, c16 = lane & 15;
+  const int Hkv = P.num_kv_heads, Hq = P.num_q_heads, G = Hq / Hkv;
+  const int req = blockIdx.x / Hkv, h = blockIdx.x - req * Hkv;
+  const int q0 = P.query_start_loc[req];
+  const int q_len = P.query_start_loc[req + 1] - q0;
+  const int ctx = P.seq_lens[req];
+  const int n_rows = q_len * G;
+  const int row0 = blockIdx.z * (MTQ * 16);
+  if (row0 >= n_rows) return;
+
+  const int n_parts = P.n_splits * 4;
+  const int part = blockIdx.y * 4 + wave;
+  const int tiles_total = (ctx + kTile - 1) / kTile;
+  const int tiles_per_part = (tiles_total + n_parts - 1) / n_parts;
+  const int t_begin = part * tiles_per_part * kTile;
+  const int t_end = min(ctx, t_begin + tiles_per_part * kTile);
+
+  const int64_t kv_row = static_cast<int64_t>(Hkv) * kD;  // elements between consecutive tokens of a page
+  const int32_t* btab = P.block_table + static_cast<int64_t>(req) * P.max_blocks;
+
+  // ---- query fragments (B operand of S^T = K Q^T): lane (row c16, k-group g) ----------------------
+  uint4 qf[MTQ][4];
+  int row_pos[MTQ];  // query position of this lane's row
+  bool row_ok[MTQ];
+#pragma unroll
+  for (int mt = 0; mt < MTQ; ++mt) {
+    const int rr = row0 + mt * 16 + c16;
+    row_ok[mt] = rr < n_rows;
+    const int rc = min(rr, n_rows - 1);
+    const int pos = rc / G, gq = rc - pos * G;
+    row_pos[mt] = pos;
+    const uint16_t* qp = P.q + static_cast<int64_t>(q0 + pos) * P.q_stride + static_cast<int64_t>(h * G + gq) * kD + 8 * g;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[mt][s] = *reinterpret_cast<const uint4*>(qp + 32 * s);
+  }
+
+  float m_run[MTQ], l_run[MTQ];
+  f32x4 o_acc[MTQ][8];
+#pragma unroll
+  for (int mt = 0; mt < MTQ; ++mt) {
+    m_run[mt] = -INFINITY;
+    l_run[mt] = 0.0f;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) o_acc[mt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  uint4* vt = v_lds[wave];
+
+  // loads of one 32-token tile: K as MFMA A fragments (token c16, d = 32 s + 8 g ..), V row-contiguous
+  auto load_tile = [&](int tt, uint4(&kf)[2][4], uint4(&vf)[8]) {
+#pragma unroll
+    for (int th = 0; th < 2; ++th) {
+      const int tok = min(tt + 16 * th + c16, ctx - 1);  // never touch pages past the context
+      const int blk = btab[tok / P.block_size];
+      const uint16_t* kp = P.k_cache + static_cast<int64_t>(blk) * P.block_stride +
+                           static_cast<int64_t>(tok % P.block_size) * kv_row + h * kD + 8 * g;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kf[th][s] = *reinterpret_cast<const uint4*>(kp + 32 * s);
+    }
+#pragma unroll
+    for (int iv = 0; iv < 8; ++iv) {
+      const int tok = min(tt + 4 * iv + g, ctx - 1);
+      const int blk = btab[tok / P.block_size];
+      const uint16_t* vp = P.v_cache + static_cast<int64_t>(blk) * P.block_stride +
+                           static_cast<int64_t>(tok % P.block_size) * kv_row + h * kD + 8 * c16;
+      vf[iv] = *reinterpret_cast<const uint4*>(vp);
+    }
+  };
+
+  if (t_begin < t_end) {
+    uint4 k_cur[2][4], v_stage[8];
+    load_tile(t_begin, k_cur, v_stage);
+#pragma unroll
+    for (int iv = 0; iv < 8; ++iv) vt[(4 * iv + g) * 16 + c16] = v_stage[iv];
+
+    for (int tt = t_begin; tt < t_end; tt += kTile) {
+      const bool more = tt + kTile < t_end;
+      uint4 k_next[2][4];
+      if (more) load_tile(tt + kTile, k_next, v_stage);
+
+      // ---- S^T tiles and online softmax, per 16-row query tile ---------------------------------
+      bf16x8 pfrag[MTQ];
+#pragma unroll
+      for (int mt = 0; mt < MTQ; ++mt) {
+        f32x4 st[2];
+#pragma unroll
+        for (int th = 0; th < 2; ++th) {
+          st[th] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            st[th] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k_cur[th][s]),
+                                                             __builtin_bit_cast(bf16x8, qf[mt][s]), st[th], 0, 0, 0);
+        }
+        // lane: query row c16, tokens tt + 16 th + 4 g + e
+        const int limit = ctx - q_len + row_pos[mt];
+        float sc[8];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int th = 0; th < 2; ++th)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int tok = tt + 16 * th + 4 * g + e;
+            const bool vis = row_ok[mt] && tok < t_end && tok <= limit;
+            const float v = vis ? st[th][e] * P.sm_scale : -INFINITY;
+            sc[th * 4 + e] = v;
+            tmax = fmaxf(tmax, v);
+          }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run[mt], tmax);
+        float alpha = 1.0f, psum = 0.0f;
+        float pv[8];
+        if (m_new == -INFINITY) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pv[e] = 0.0f;
+        } else {
+          alpha = __expf(m_run[mt] - m_new);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            pv[e] = __expf(sc[e] - m_new);
+            psum += pv[e];
+          }
+        }
+        psum += __shfl_xor(psum, 16);
+        psum += __shfl_xor(psum, 32);
+        l_run[mt] = l_run[mt] * alpha + psum;
+        m_run[mt] = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) o_acc[mt][dt] *= alpha;
+        bf16x8 pf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[e] = static_cast<__bf16>(pv[e]);
+        pfrag[mt] = pf;
+      }
+
+      // ---- O^T += V^T P^T : A = V^T fragment via transposing LDS reads -----------------------------
+      {
+        const int q4 = c16 >> 2, p4 = c16 & 3;
+        const uint16_t* vbase = reinterpret_cast<const uint16_t*>(vt);
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+          const uint16_t* a_lo = vbase + (4 * g + q4) * 128 + dt * 16 + 4 * p4;
+          const uint16_t* a_hi = a_lo + 16 * 128;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(const_cast<uint16_t*>(a_lo)));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(const_cast<uint16_t*>(a_hi)));
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          const bf16x8 vfrag = __builtin_bit_cast(bf16x8, both);
+#pragma unroll
+          for (int mt = 0; mt < MTQ; ++mt)
+            o_acc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pfrag[mt], o_acc[mt][dt], 0, 0, 0);
+        }
+      }
+
+      if (more) {
+#pragma unroll
+        for (int iv = 0; iv < 8; ++iv) vt[(4 * iv + g) * 16 + c16] = v_stage[iv];
+#pragma unroll
+        for (int th = 0; th < 2; ++th)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) k_cur[th][s] = k_next[th][s];
+      }
+    }
+  }
+
+  // ---- partial result of this wave: O^T accumulator -> ws_o[part][row][d], (m, l) -> ws_ml ----------
+#pragma unroll
+  for (int mt = 0; mt < MTQ; ++mt) {
+    if (!row_ok[mt]) continue;
+    const int rr = row0 + mt * 16 + c16;
+    const int pos = rr / G, gq = rr - pos * G;
+    const int64_t grow = static_cast<int64_t>(q0 + pos) * Hq + h * G + gq;
+    float* op = P.ws_o + (static_cast<int64_t>(part) * P.total_rows + grow) * kD + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+      *reinterpret_cast<float4*>(op + dt * 16) =
+          make_float4(o_acc[mt][dt][0], o_acc[mt][dt][1], o_acc[mt][dt][2], o_acc[mt][dt][3]);
+    if (g == 0) {
+      float* mp = P.ws_ml + (static_cast<int64_t>(part) * P.total_rows + grow) * 2;
+      mp[0] = m_run[mt];
+      mp[1] = l_run[mt];
+    }
+  }
+}
+
+// one wavefront per output row (token, q head): merge the n_parts partials
+__global__ void __launch_bounds__(256)
+verify_attn_combine_kernel(const float* __restrict__ ws_o, const float* __restrict__ ws_ml, int n_parts, int total_rows,
+                           int num_q_heads, uint16_t* __restrict__ out, int64_t out_stride) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= total_rows) return;
+  float M = -INFINITY;
+  for (int p = lane; p < n_parts; p += 64) M = fmaxf(M, ws_ml[(static_cast<int64_t>(p) * total_rows + row) * 2]);
+  for (int off = 32; off > 0; off >>= 1) M = fmaxf(M, __shfl_xor(M, off));
+  float acc0 = 0.0f, acc1 = 0.0f, L = 0.0f;
+  for (int p = 0; p < n_parts; ++p) {
+    const float* ml = ws_ml + (static_cast<int64_t>(p) * total_rows + row) * 2;
+    const float mp = ml[0];
+    if (mp == -INFINITY) continue;
+    const float w = __expf(mp - M);
+    L += w * ml[1];
+    const float2 o = *reinterpret_cast<const float2*>(ws_o + (static_cast<int64_t>(p) * total_rows + row) * kD + 2 * lane);
+    acc0 += w * o.x;
+    acc1 += w * o.y;
+  }
+  const float inv = L > 0.0f ? 1.0f / L : 0.0f;
+  const int tok = row / num_q_heads, head = row - tok * num_q_heads;
+  uint16_t* op = out + static_cast<int64_t>(tok) * out_stride + static_cast<int64_t>(head) * kD + 2 * lane;
+  const uint32_t packed = static_cast<uint32_t>(f32_to_bf16(acc0 * inv)) | (static_cast<uint32_t>(f32_to_bf16(acc1 * inv)) << 16);
+  *reinterpret_cast<uint32_t*>(op) = packed;
+}
+
+static int pick_splits(int batch, int num_kv_heads, int m_groups, int max_seq_len) {
+  const int64_t base_waves = static_cast<int64_t>(batch) * num_kv_heads * m_groups * 4;
+  int64_t s = (6144 + base_waves - 1) / base_waves;  // ~3 waves per SIMD chip-wide
+  const int max_tiles = (max_seq_len + kTile - 1) / kTile;
+  const int64_t cap = std::max(1, (max_tiles + 7) / 8);  // at least ~2 tiles per wave
+  if (s > cap) s = cap;
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  return static_cast<int>(s);
+}
+
+}  // namespace aic
+
+using namespace aic;
+
+extern "C" {
+
+size_t aic_verify_attention_workspace_bytes(int num_tokens, int num_q_heads, int head_size, int num_splits_max) {
+  const size_t rows = static_cast<size_t>(num_tokens) * num_q_heads;
+  const size_t parts = static_cast<size_t>(num_splits_max > 0 ? num_splits_max : 64) * 4;
+  return parts * rows * (static_cast<size_t>(head_size) + 2) * sizeof(float) + 256;
+}
+
+int aic_verify_attention(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
+                         int64_t block_stride, int kv_dtype, const float* k_scale, const float* v_scale,
+                         const int32_t* block_table, int max_blocks_per_seq, const int32_t* seq_lens,
+                         const int32_t* query_start_loc, int batch, int num_tokens, int max_q_len, int num_q_heads,
+                         int num_kv_heads, int head_size, int block_size, float sm_scale, void* out,
+                         int64_t out_stride, void* workspace, size_t workspace_bytes, int max_seq_len, void* stream) {
+  if (batch == 0 || num_tokens == 0) return AIC_OK;
+  AIC_REQUIRE(q && k_cache && v_cache && block_table && seq_lens && query_start_loc && out && workspace,
+              "null pointer argument to aic_verify_attention");
+  AIC_REQUIRE(batch > 0 && num_tokens > 0 && max_q_len > 0 && num_q_heads > 0 && num_kv_heads > 0 && block_size > 0 &&
+                  max_blocks_per_seq > 0 && max_seq_len > 0,
+              "non-positive size argument");
+  AIC_REQUIRE(num_q_heads % num_kv_heads == 0, "num_q_heads must be a multiple of num_kv_heads");
+  (void)k_scale;
+  (void)v_scale;
+  if (head_size != kD) {
+    set_error("head_size %d not supported yet (128 only)", head_size);
+    return AIC_ERR_UNSUPPORTED;
+  }
+  if (kv_dtype != AIC_DT_BF16) {
+    set_error("kv cache dtype %d not supported yet (bf16 only)", kv_dtype);
+    return AIC_ERR_UNSUPPORTED;
+  }
+  AIC_REQUIRE(q_stride % 8 == 0 && out_stride % 2 == 0 && block_stride % 8 == 0, "strides must keep 16-byte alignment");
+  AIC_NEED_DEVICE();
+
+  const int G = num_q_heads / num_kv_heads;
+  const int max_rows = max_q_len * G;
+  const int mtq = max_rows <= 16 ? 1 : 2;
+  const int m_groups = (max_rows + mtq * 16 - 1) / (mtq * 16);
+  int n_splits = pick_splits(batch, num_kv_heads, m_groups, max_seq_len);
+  const size_t rows = static_cast<size_t>(num_tokens) * num_q_heads;
+  while (n_splits > 1 && static_cast<size_t>(n_splits) * 4 * rows * (kD + 2) * sizeof(float) > workspace_bytes) --n_splits;
+  AIC_REQUIRE(static_cast<size_t>(n_splits) * 4 * rows * (kD + 2) * sizeof(float) <= workspace_bytes,
+              "workspace too small (%zu bytes)", workspace_bytes);
+
+  AttnParams P;
+  P.q = static_cast<const uint16_t*>(q);
+  P.k_cache = static_cast<const uint16_t*>(k_cache);
+  P.v_cache = static_cast<const uint16_t*>(v_cache);
+  P.block_table = block_table;
+  P.seq_lens = seq_lens;
+  P.query_start_loc = query_start_loc;
+  P.ws_o = static_cast<float*>(workspace);
+  P.ws_ml = P.ws_o + static_cast<size_t>(n_splits) * 4 * rows * kD;
+  P.q_stride = q_stride;
+  P.block_stride = block_stride;
+  P.max_blocks = max_blocks_per_seq;
+  P.num_q_heads = num_q_heads;
+  P.num_kv_heads = num_kv_heads;
+  P.block_size = block_size;
+  P.n_splits = n_splits;
+  P.total_rows = static_cast<int>(rows);
+  P.sm_scale = sm_scale;
+
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  dim3 grid(batch * num_kv_heads, n_splits, m_groups);
+  if (mtq == 1)
+    hipLaunchKernelGGL(verify_attn_kernel<1>, grid, dim3(256), 0, s, P);
+  else
+    hipLaunchKernelGGL(verify_attn_kernel<2>, grid, dim3(256), 0, s, P);
+  int rc = launch_status("verify_attn_kernel");
+  if (rc != AIC_OK) return rc;
+  hipLaunchKernelGGL(verify_attn_combine_kernel, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s, P.ws_o,
+                     P.ws_ml, n_splits * 4, static_cast<int>(rows), num_q_heads, static_cast<uint16_t*>(out), out_stride);
+  return launch_status("verify_attn_combine_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,196 @@
+"""torch-facing wrappers over the C ABI (include/arctic_hip.h).  PyTorch is plumbing here: it owns
+device memory and streams; every op below is a single call into libarctic_hip.so on the current
+stream.  Nothing falls back to torch or the CPU — a missing library or device raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _native as N
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("arcticinference_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+
+
+# ------------------------------------------------------------------------------------------------
+# A16 bulk KV write — same signature as arctic_inference.py_custom_ops.reshape_and_cache_flash_bulk
+# (/root/reference/arctic_inference/py_custom_ops.py:40-54)
+# ------------------------------------------------------------------------------------------------
+_KV_DTYPES = {"auto": None, "fp8": N.DT_FP8_E4M3, "fp8_e4m3": N.DT_FP8_E4M3, "fp8_e5m2": N.DT_FP8_E5M2}
+
+
+def reshape_and_cache_flash_bulk(keys: torch.Tensor, values: torch.Tensor, key_caches: List[torch.Tensor],
+                                 value_caches: List[torch.Tensor], slot_mapping: torch.Tensor, kv_cache_dtype: str,
+                                 k_scales: List[torch.Tensor], v_scales: List[torch.Tensor], num_heads: int,
+                                 head_size: int) -> None:
+    L = len(key_caches)
+    if L == 0:
+        return
+    # same checks as the reference launcher (kernels.cu:103-106)
+    if not (L == len(value_caches) == len(k_scales) == len(v_scales)):
+        raise RuntimeError("key_caches, value_caches, k_scales and v_scales must have the same length")
+    if kv_cache_dtype not in _KV_DTYPES:
+        raise RuntimeError(f"unsupported kv cache dtype '{kv_cache_dtype}'")
+    _need_cuda(keys, values, slot_mapping, *key_caches, *value_caches)
+    if slot_mapping.dtype != torch.int64:
+        raise RuntimeError("slot_mapping must be int64")
+    src = N.torch_dtype_code(keys.dtype)
+    kvd = _KV_DTYPES[kv_cache_dtype]
+    if kvd is None:
+        kvd = src
+        if key_caches[0].dtype != keys.dtype:
+            raise RuntimeError("kv_cache_dtype 'auto' needs caches of the source dtype")
+    block_size = key_caches[0].size(1)
+    block_stride = key_caches[0].stride(0)
+    if block_stride != value_caches[0].stride(0):
+        raise RuntimeError("key and value caches must share the block stride")
+    VP = ctypes.c_void_p * L
+    kc = VP(*[c.data_ptr() for c in key_caches])
+    vc = VP(*[c.data_ptr() for c in value_caches])
+    ks = VP(*[s.data_ptr() for s in k_scales])
+    vs = VP(*[s.data_ptr() for s in v_scales])
+    N.check(N.lib().aic_reshape_and_cache_flash_bulk(
+        keys.data_ptr(), values.data_ptr(), kc, vc, slot_mapping.data_ptr(), slot_mapping.size(0), L,
+        int(num_heads), int(head_size), int(block_size), int(block_stride), int(keys.stride(0)),
+        int(values.stride(0)), src, kvd, ks, vs, N.current_stream_ptr()))
+
+
+# ------------------------------------------------------------------------------------------------
+# A6 rejection acceptance
+# ------------------------------------------------------------------------------------------------
+class RejectionResult:
+    __slots__ = ("output_token_ids", "num_accepted", "last_token", "hidden_index")
+
+    def __init__(self, output_token_ids, num_accepted, last_token, hidden_index):
+        self.output_token_ids = output_token_ids
+        self.num_accepted = num_accepted
+        self.last_token = last_token
+        self.hidden_index = hidden_index
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    key = (device.index, "ws")
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def rejection_sample(target_logits: torch.Tensor, draft_token_ids: torch.Tensor, cu_num_draft_tokens: torch.Tensor,
+                     bonus_token_ids: torch.Tensor, max_spec_len: int, temperature: Optional[torch.Tensor] = None,
+                     uniform_probs: Optional[torch.Tensor] = None, exp_noise: Optional[torch.Tensor] = None
+                     ) -> RejectionResult:
+    """out[B, max_spec_len+1] int32 (-1 padded) as vLLM's RejectionSampler returns it for
+    draft_probs=None (call site model_runner.py:405-411), plus the proposer inputs of the next step."""
+    _need_cuda(target_logits, draft_token_ids, cu_num_draft_tokens, bonus_token_ids)
+    B = cu_num_draft_tokens.numel()
+    rows = draft_token_ids.numel()
+    V = target_logits.size(-1) if rows else 1
+    dev = cu_num_draft_tokens.device
+    out = torch.empty((B, max_spec_len + 1), dtype=torch.int32, device=dev)
+    nacc = torch.empty(B, dtype=torch.int32, device=dev)
+    last = torch.empty(B, dtype=torch.int32, device=dev)
+    hidx = torch.empty(B, dtype=torch.int32, device=dev)
+    ws = _workspace(N.lib().aic_rejection_workspace_bytes(rows, V), dev)
+    draft = draft_token_ids.to(torch.int32)
+    cu = cu_num_draft_tokens.to(torch.int32)
+    bonus = bonus_token_ids.reshape(-1).to(torch.int32)
+    dt = N.torch_dtype_code(target_logits.dtype) if rows else N.DT_F32
+    stride = target_logits.stride(0) if rows else 0
+    if temperature is None:
+        N.check(N.lib().aic_rejection_greedy(_ptr(target_logits) if rows else None, dt, stride, V, draft.data_ptr(),
+                                             cu.data_ptr(), bonus.data_ptr(), B, rows, max_spec_len, out.data_ptr(),
+                                             nacc.data_ptr(), last.data_ptr(), hidx.data_ptr(), ws.data_ptr(),
+                                             N.current_stream_ptr()))
+    else:
+        N.check(N.lib().aic_rejection_random(_ptr(target_logits) if rows else None, dt, stride, V, draft.data_ptr(),
+                                             cu.data_ptr(), bonus.data_ptr(), temperature.float().data_ptr(),
+                                             uniform_probs.double().data_ptr(), exp_noise.float().data_ptr(), B, rows,
+                                             max_spec_len, out.data_ptr(), nacc.data_ptr(), last.data_ptr(),
+                                             hidx.data_ptr(), ws.data_ptr(), N.current_stream_ptr()))
+    return RejectionResult(out, nacc, last, hidx)
+
+
+# ------------------------------------------------------------------------------------------------
+# A5 verify attention
+# ------------------------------------------------------------------------------------------------
+def verify_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_table: torch.Tensor,
+                     seq_lens: torch.Tensor, query_start_loc: torch.Tensor, max_q_len: int, max_seq_len: int,
+                     sm_scale: float, out: Optional[torch.Tensor] = None, num_splits_max: int = 64) -> torch.Tensor:
+    """q [T, Hq, D] (token stride may exceed Hq*D: a view into an all-to-all receive buffer works),
+    caches [num_blocks, block_size, Hkv, D]; returns [T, Hq, D]."""
+    _need_cuda(q, k_cache, v_cache, block_table, seq_lens, query_start_loc)
+    T, Hq, D = q.shape
+    nb, bs, Hkv, D2 = k_cache.shape
+    assert D == D2 and q.stride(2) == 1 and q.stride(1) == D
+    if out is None:
+        out = torch.empty((T, Hq, D), dtype=q.dtype, device=q.device)
+    B = seq_lens.numel()
+    wsb = N.lib().aic_verify_attention_workspace_bytes(T, Hq, D, num_splits_max)
+    ws = _workspace(wsb, q.device)
+    kvd = N.torch_dtype_code(k_cache.dtype)
+    N.check(N.lib().aic_verify_attention(
+        q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(), k_cache.stride(0), kvd, None, None,
+        block_table.data_ptr(), block_table.size(1), seq_lens.data_ptr(), query_start_loc.data_ptr(), B, T,
+        int(max_q_len), Hq, Hkv, D, bs, float(sm_scale), out.data_ptr(), out.stride(0), ws.data_ptr(), ws.numel(),
+        int(max_seq_len), N.current_stream_ptr()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# A12 Ulysses repartition copies
+# ------------------------------------------------------------------------------------------------
+def ulysses_pack_qkv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, sp: int) -> torch.Tensor:
+    """q [n, SP*qw], k/v [n, SP*kw] -> send [SP*n, qw+2kw] (rank-major), ulysses.py:493-499."""
+    _need_cuda(q, k, v)
+    n = q.size(0)
+    qw, kw = q.size(1) // sp, k.size(1) // sp
+    send = torch.empty((sp * n, qw + 2 * kw), dtype=q.dtype, device=q.device)
+    N.check(N.lib().aic_ulysses_pack_qkv(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0),
+                                         v.stride(0), send.data_ptr(), n, sp, qw, kw, N.current_stream_ptr()))
+    return send
+
+
+def ulysses_split_qkv(recv: torch.Tensor, qw: int, kw: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    _need_cuda(recv)
+    rows = recv.size(0)
+    q = torch.empty((rows, qw), dtype=recv.dtype, device=recv.device)
+    k = torch.empty((rows, kw), dtype=recv.dtype, device=recv.device)
+    v = torch.empty((rows, kw), dtype=recv.dtype, device=recv.device)
+    N.check(N.lib().aic_ulysses_split_qkv(recv.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), rows, qw, kw,
+                                          N.current_stream_ptr()))
+    return q, k, v
+
+
+def ulysses_unpack_out(recv: torch.Tensor, sp: int) -> torch.Tensor:
+    """recv [SP*n, w] (rank-major) -> out [n, SP*w], ulysses.py:515-517."""
+    _need_cuda(recv)
+    n = recv.size(0) // sp
+    w = recv.size(1)
+    out = torch.empty((n, sp * w), dtype=recv.dtype, device=recv.device)
+    N.check(N.lib().aic_ulysses_unpack_out(recv.data_ptr(), out.data_ptr(), n, sp, w, N.current_stream_ptr()))
+    return out
+
+
+def quantize_fp8_per_tensor(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    _need_cuda(x)
+    x = x.contiguous()
+    q = torch.empty(x.shape, dtype=torch.float8_e4m3fn, device=x.device)
+    scale = torch.empty(1, dtype=torch.float32, device=x.device)
+    N.check(N.lib().aic_quantize_fp8_per_tensor(x.data_ptr(), q.data_ptr(), scale.data_ptr(), x.numel(),
+                                                N.current_stream_ptr()))
+    return q, scale

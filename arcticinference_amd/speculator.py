@@ -1,0 +1,251 @@
+"""Host side of the Arctic LSTM speculator ("sum_lstm") draft model.
+
+Mirrors the interface of the reference's ArcticLSTMSpeculator
+(/root/reference/arctic_inference/vllm/spec_dec/arctic_speculator.py:404-902): constructor from an
+HF-style config, `load_weights(iter[(name, tensor)])` with the same checkpoint-name handling
+(:874-902), `generate_proposals(input_ids[B], previous_hidden_states[B,H], k) -> int64 [B,k]`
+(:753-866), `padding_size` (:39-44), and the vocab-parallel LM head whose group is max(TP,SP) wide
+(vocab_parallel_embedding.py:20-35) with the packed (value, index) all-gather (:733-744).
+
+All arithmetic runs in libarctic_hip.so (csrc/lstm_speculator.hip); this file owns weights, the
+distributed exchange and argument checking.  The k-head loop is one native call for tp_size == 1;
+HIP-graph capture (`use_graph=True`) replays it per padded batch size like the reference's
+CUDA-graph cache keyed on padding_size (:98-99, :806-842).
+"""
+from __future__ import annotations
+
+import collections
+import ctypes
+import math
+from dataclasses import dataclass
+from typing import Dict, Iterable, Optional, Tuple
+
+import torch
+
+from . import _native as N
+
+DEFAULT_VOCAB_PADDING_SIZE = 64  # vocab_parallel_embedding.py:17
+
+
+def padding_size(size: int) -> int:
+    """arctic_speculator.py:39-44 (same arithmetic; also exported by the library)."""
+    mult = (1 << (size - 1).bit_length()) // 4
+    if mult < 1:
+        return size
+    return (size + mult - 1) // mult * mult
+
+
+def pad_vocab_size(vocab_size: int, pad_to: int = DEFAULT_VOCAB_PADDING_SIZE) -> int:
+    return ((vocab_size + pad_to - 1) // pad_to) * pad_to
+
+
+def _first_dim(v) -> int:
+    # the HF config stores "4096" or "4096.4096" strings (arctic_speculator.py:423-428)
+    if isinstance(v, str):
+        return int(v.split(".")[0])
+    if isinstance(v, (list, tuple)):
+        return int(v[0])
+    return int(v)
+
+
+@dataclass
+class LSTMSpeculatorConfig:
+    vocab_size: int
+    input_hidden_dim: int
+    inner_dim: object = "4096"
+    emb_dim: object = "4096"
+    proj_dim: object = "4096"
+    n_predict: int = 3
+    num_lookahead_tokens: int = 3
+    tie_weights: bool = True
+    tie_lstm_embs: bool = True
+    scale_input: bool = True
+    method: str = "sum_lstm"
+
+
+class ArcticLSTMSpeculator:
+    def __init__(self, config: LSTMSpeculatorConfig, max_num_seqs: int = 64, tp_size: int = 1, tp_rank: int = 0,
+                 tp_group=None, device: str = "cuda", quantize_lm_head: bool = True, use_graph: bool = False):
+        if config.method != "sum_lstm":
+            raise NotImplementedError("only the sum_lstm speculator is on the MI355X path (SURVEY §8f-3)")
+        assert config.tie_weights and config.tie_lstm_embs, "sum_lstm requires tied weights (arctic_speculator.py:545,663)"
+        self.config = config
+        self.n_predict = config.n_predict
+        self.vocab_size = config.vocab_size
+        self.input_hidden_dim = config.input_hidden_dim
+        self.inner_dim = _first_dim(config.inner_dim)
+        assert _first_dim(config.emb_dim) == self.inner_dim == _first_dim(config.proj_dim), \
+            "generate_states needs proj_dim == emb_dim == inner_dim (arctic_speculator.py:667-688)"
+        self.max_speculative_tokens = config.num_lookahead_tokens
+        self.scale_input = config.scale_input
+        self.quantize_lm_head = quantize_lm_head
+        self.tp_size, self.tp_rank, self.tp_group = tp_size, tp_rank, tp_group
+        self.device = torch.device(device)
+        self.max_batch = min(64, padding_size(max_num_seqs))
+        self.use_graph = use_graph
+        self._graphs: Dict[Tuple[int, int], object] = {}
+        self.state_weight = 0.5 ** (0.5 / config.n_predict)
+        self.emb_weight = math.sqrt((1 - self.state_weight ** 2) * (self.inner_dim / 2))
+        # vocab-parallel LM head shard (vocab_parallel_embedding.py:72-75, :409-423)
+        padded = pad_vocab_size(self.vocab_size)
+        assert padded % tp_size == 0
+        self.shard_size = padded // tp_size
+        self.shard_start = tp_rank * self.shard_size
+        self.shard_rows = max(0, min(self.vocab_size, self.shard_start + self.shard_size) - self.shard_start)
+        self.weights: Dict[str, torch.Tensor] = {}
+        self._h = None
+        self._static = None
+
+    # -- weights -------------------------------------------------------------------------------------
+    def load_weights(self, weights: Iterable[Tuple[str, torch.Tensor]]):
+        """Same name handling as the reference loader (arctic_speculator.py:874-902)."""
+        w = collections.OrderedDict((k.replace("speculator.", ""), v) for k, v in weights)
+        for drop in ("input_emb.0.weight", "cell_emb.0.weight", "output_emb.0.weight"):
+            w.pop(drop, None)
+        for i in (0, 1):
+            parts = [w.pop(f"{g}_proj.{i}.weight", None) for g in ("forget", "input", "output", "cell")]
+            if all(p is not None for p in parts):
+                w[f"projs.{i}.weight"] = torch.cat(parts)  # [4P, in] in f|i|o|c order (:886-891)
+        need = ["forget_emb.0.weight", "projs.0.weight", "projs.1.weight", "cell_ln.0.weight", "cell_ln.0.bias",
+                "state_ln.0.weight", "state_ln.0.bias", "head.0.weight"]
+        for n in need:
+            if n not in w:
+                raise KeyError(f"speculator checkpoint is missing '{n}'")
+        Ds, H = self.inner_dim, self.input_hidden_dim
+        assert w["projs.0.weight"].shape == (4 * Ds, H) and w["projs.1.weight"].shape == (4 * Ds, Ds)
+        assert w["forget_emb.0.weight"].shape == (self.vocab_size, Ds)
+        assert w["head.0.weight"].shape == (self.vocab_size, Ds)
+        dev = self.device
+        bf = lambda t: t.to(device=dev, dtype=torch.bfloat16).contiguous()
+        head_local = w["head.0.weight"][self.shard_start:self.shard_start + self.shard_rows]
+        self.weights = {n: bf(w[n]) for n in need if n != "head.0.weight"}
+        self.weights["head.0.weight"] = bf(head_local)
+        self._create_native()
+
+    def _create_native(self):
+        if self._h is not None:
+            N.lib().aic_lstm_destroy(self._h)
+        W = self.weights
+        cfg = N.LstmConfig(vocab_size=self.shard_rows, vocab_offset=self.shard_start,
+                           input_hidden_dim=self.input_hidden_dim, inner_dim=self.inner_dim,
+                           n_predict=self.n_predict, scale_input=int(self.scale_input), max_batch=self.max_batch,
+                           head_fp8_max_batch=32 if self.quantize_lm_head else 0)  # fp8 head when batch <= 32 (:726-728)
+        wt = N.LstmWeights(forget_emb=W["forget_emb.0.weight"].data_ptr(), proj0=W["projs.0.weight"].data_ptr(),
+                           proj1=W["projs.1.weight"].data_ptr(), cell_ln_w=W["cell_ln.0.weight"].data_ptr(),
+                           cell_ln_b=W["cell_ln.0.bias"].data_ptr(), state_ln_w=W["state_ln.0.weight"].data_ptr(),
+                           state_ln_b=W["state_ln.0.bias"].data_ptr(), head=W["head.0.weight"].data_ptr(),
+                           head_fp8=None, head_fp8_scale=0.0)
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            N.check(N.lib().aic_lstm_create(ctypes.byref(cfg), ctypes.byref(wt), ctypes.byref(h)))
+        self._h = h
+        # the library keeps its own fragment-major copies of projs / head; the row-major LM head and
+        # projections are no longer needed on the device
+        for n in ("projs.0.weight", "projs.1.weight", "head.0.weight"):
+            self.weights[n] = None
+        mb = self.max_batch
+        self._static = {
+            "hidden": torch.zeros(mb, self.input_hidden_dim, dtype=torch.bfloat16, device=self.device),
+            "tokens": torch.zeros(mb, dtype=torch.int32, device=self.device),
+            "out": torch.zeros(mb, self.max_speculative_tokens, dtype=torch.int64, device=self.device),
+            "vals": torch.zeros(mb, self.max_speculative_tokens, dtype=torch.float32, device=self.device),
+        }
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None:
+            try:
+                N.lib().aic_lstm_destroy(self._h)
+            except Exception:
+                pass
+            self._h = None
+
+    # -- drafting --------------------------------------------------------------------------------------
+    def generate_proposals(self, input_ids: torch.Tensor, previous_hidden_states: torch.Tensor,
+                           num_predict_tokens: int, hidden_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if num_predict_tokens > self.max_speculative_tokens:
+            raise ValueError(f"Max speculative tokens for model is {self.max_speculative_tokens}, but "
+                             f"{num_predict_tokens} were requested")
+        if self._h is None:
+            raise RuntimeError("load_weights() has not been called")
+        B = input_ids.size(0)
+        if B > self.max_batch:
+            raise ValueError(f"batch {B} exceeds max_num_seqs padding {self.max_batch}")
+        if not previous_hidden_states.is_cuda:
+            raise RuntimeError("the speculator runs on the GPU only; there is no CPU fallback")
+        k = num_predict_tokens
+        hs = previous_hidden_states
+        if hs.dtype != torch.bfloat16 or not hs.is_contiguous():
+            hs = hs.to(torch.bfloat16).contiguous()
+        toks = input_ids.to(torch.int32)
+        hidx = None if hidden_index is None else hidden_index.to(torch.int32)
+        stream = N.current_stream_ptr()
+        if self.tp_size == 1:
+            out = torch.empty((B, k), dtype=torch.int64, device=self.device)
+            if self.use_graph and hidx is None:
+                return self._replay_graph(hs, toks, B, k)
+            N.check(N.lib().aic_lstm_propose(self._h, hs.data_ptr(), _p(hidx), toks.data_ptr(), B, k, out.data_ptr(),
+                                             None, stream))
+            return out
+        # vocab-parallel: local (value, index) per head, one all-gather of 2B int64, arg-max over ranks
+        import torch.distributed as dist
+        N.check(N.lib().aic_lstm_begin(self._h, hs.data_ptr(), _p(hidx), B, stream))
+        outs = []
+        last = toks
+        tok_l = torch.empty(B, dtype=torch.int64, device=self.device)
+        val_l = torch.empty(B, dtype=torch.float32, device=self.device)
+        for head in range(k):
+            N.check(N.lib().aic_lstm_head(self._h, head, last.data_ptr(), B, tok_l.data_ptr(), val_l.data_ptr(),
+                                          N.current_stream_ptr()))
+            packed = torch.cat([val_l.to(torch.float64).view(torch.int64), tok_l])
+            gathered = torch.empty(self.tp_size * 2 * B, dtype=torch.int64, device=self.device)
+            dist.all_gather_into_tensor(gathered, packed, group=self.tp_group)
+            g = gathered.view(self.tp_size, 2, B)
+            vals = g[:, 0, :].view(torch.float64)
+            idxs = g[:, 1, :]
+            win = torch.argmax(vals, dim=0, keepdim=True)  # first maximum = lowest rank = lowest index
+            nxt = torch.gather(idxs, 0, win).reshape(B)
+            outs.append(nxt.unsqueeze(1))
+            last = nxt.to(torch.int32)
+        return torch.cat(outs, dim=-1)
+
+    def _replay_graph(self, hs, toks, B, k):
+        pad = padding_size(B)
+        st = self._static
+        st["hidden"][:B].copy_(hs)
+        st["tokens"][:B].copy_(toks)
+        key = (pad, k)
+        g = self._graphs.get(key)
+        if g is None:
+            # warm up once outside capture, then capture the k-head loop for this padded batch
+            N.check(N.lib().aic_lstm_propose(self._h, st["hidden"].data_ptr(), None, st["tokens"].data_ptr(), pad, k,
+                                             st["out"].data_ptr(), None, N.current_stream_ptr()))
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                N.check(N.lib().aic_lstm_propose(self._h, st["hidden"].data_ptr(), None, st["tokens"].data_ptr(), pad,
+                                                 k, st["out"].data_ptr(), None, N.current_stream_ptr()))
+            self._graphs[key] = g
+        g.replay()
+        return st["out"].view(-1)[: pad * k].view(pad, k)[:B].clone()
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def random_lstm_weights(cfg: LSTMSpeculatorConfig, seed: int = 0, std: float = 0.02, device="cpu"
+                        ) -> "collections.OrderedDict[str, torch.Tensor]":
+    """Seeded synthetic checkpoint with the reference's parameter names (no real weights travel)."""
+    g = torch.Generator().manual_seed(seed)
+    Ds, H, V = _first_dim(cfg.inner_dim), cfg.input_hidden_dim, cfg.vocab_size
+    r = lambda *s: (torch.randn(*s, generator=g) * std).to(torch.bfloat16).to(device)
+    w = collections.OrderedDict()
+    w["forget_emb.0.weight"] = r(V, Ds)
+    for gate in ("forget", "input", "output", "cell"):
+        w[f"{gate}_proj.0.weight"] = r(Ds, H)
+        w[f"{gate}_proj.1.weight"] = r(Ds, Ds)
+    for ln in ("cell_ln", "state_ln"):
+        w[f"{ln}.0.weight"] = (1.0 + 0.1 * torch.randn(Ds, generator=g)).to(torch.bfloat16).to(device)
+        w[f"{ln}.0.bias"] = (0.1 * torch.randn(Ds, generator=g)).to(torch.bfloat16).to(device)
+    w["head.0.weight"] = r(V, Ds)
+    return w

@@ -1,0 +1,264 @@
+"""SuffixCache / SuffixSpecResult / SuffixTree with the reference's names, arguments, defaults and
+errors (/root/reference/arctic_inference/common/suffix_cache/suffix_cache.py:24-222 and the pybind
+class of csrc/suffix_cache/pybind.cc:24-38), backed by libarctic_hip.so.
+
+Tree updates run in the library's host arena; candidate matching runs on the MI355X.  The extra
+method `speculate_batch` is what the model-runner patch uses: one device round trip for the whole
+engine step instead of one host call per request (model_runner.py:680-744 loops on the CPU).
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+from typing import Hashable, List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import _native as N
+
+
+@dataclass
+class SuffixSpecResult:
+    """Same fields as the reference dataclass (suffix_cache.py:24-54)."""
+    token_ids: List[int] = field(default_factory=list)
+    parents: List[int] = field(default_factory=list)
+    probs: List[float] = field(default_factory=list)
+    score: float = 0.0
+    match_len: int = 0
+
+    @staticmethod
+    def from_candidate(candidate) -> "SuffixSpecResult":
+        return SuffixSpecResult(token_ids=list(candidate.token_ids), parents=list(candidate.parents),
+                                probs=list(candidate.probs), score=candidate.score,
+                                match_len=candidate.match_len)
+
+
+Candidate = SuffixSpecResult  # the pybind `Candidate` has the same five fields (pybind.cc:25-30)
+
+
+def _i32(seq) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(seq, dtype=np.int32).reshape(-1))
+
+
+def _stream() -> int:
+    try:
+        return N.current_stream_ptr()
+    except Exception:
+        return 0
+
+
+class SuffixTree:
+    """Drop-in for `arctic_inference.common.suffix_cache._C.SuffixTree`."""
+
+    def __init__(self, max_depth: int, _handle=None, _owner=None):
+        self._owner = _owner
+        if _handle is not None:
+            self._h = ctypes.c_void_p(_handle)
+        else:
+            h = N.lib().aic_st_create(int(max_depth))
+            if not h:
+                raise ValueError(N.lib().aic_last_error().decode())
+            self._h = ctypes.c_void_p(h)
+        self._max_depth = int(max_depth)
+
+    def __del__(self):
+        if getattr(self, "_owner", None) is None and getattr(self, "_h", None):
+            N.lib().aic_st_destroy(self._h)
+            self._h = None
+
+    def num_seqs(self) -> int:
+        return N.lib().aic_st_num_seqs(self._h)
+
+    def append(self, seq_id: int, token: int) -> None:
+        N.check(N.lib().aic_st_append(self._h, int(seq_id), int(token)))
+
+    def extend(self, seq_id: int, tokens: Sequence[int]) -> None:
+        a = _i32(tokens)
+        N.check(N.lib().aic_st_extend(self._h, int(seq_id), a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), a.size))
+
+    def speculate(self, pattern: Sequence[int], max_spec_tokens: int, max_spec_factor: float = 1.0,
+                  max_spec_offset: float = 0.0, min_token_prob: float = 0.1,
+                  use_tree_spec: bool = False) -> SuffixSpecResult:
+        pat = _i32(pattern)
+        if pat.size == 0:
+            return SuffixSpecResult()
+        cap = max(int(max_spec_tokens), 1)
+        toks = np.empty(cap, np.int32)
+        pars = np.empty(cap, np.int32)
+        prbs = np.empty(cap, np.float32)
+        score = ctypes.c_float(0.0)
+        mlen = ctypes.c_int32(0)
+        P32 = ctypes.POINTER(ctypes.c_int32)
+        m = N.check(N.lib().aic_st_speculate(
+            self._h, pat.ctypes.data_as(P32), pat.size, int(max_spec_tokens), float(max_spec_factor),
+            float(max_spec_offset), float(min_token_prob), int(bool(use_tree_spec)),
+            toks.ctypes.data_as(P32), pars.ctypes.data_as(P32), prbs.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+            cap, ctypes.byref(score), ctypes.byref(mlen), _stream()))
+        return SuffixSpecResult(toks[:m].tolist(), pars[:m].tolist(), [float(x) for x in prbs[:m]],
+                                float(score.value), int(mlen.value))
+
+    # ---- test / debug helpers ---------------------------------------------------------------------
+    def selfcheck(self) -> int:
+        return N.check(N.lib().aic_st_selfcheck(self._h))
+
+    def export(self) -> dict:
+        """The flattened HBM image as numpy arrays, taken from the host mirror (no GPU needed)."""
+        c = [ctypes.c_int32(0) for _ in range(4)]
+        N.check(N.lib().aic_st_export(self._h, *[ctypes.byref(x) for x in c], None, None, None, None, None))
+        nn, ns, nt, nq = [int(x.value) for x in c]
+        nodes = np.zeros((nn, 8), np.int32)
+        hsh = np.zeros((ns, 4), np.int32)
+        toks = np.zeros(max(nt, 1), np.int32)
+        base = np.zeros(max(nq, 1), np.int32)
+        ids = np.zeros(max(nq, 1), np.int32)
+        N.check(N.lib().aic_st_export(self._h, *[ctypes.byref(x) for x in c], nodes.ctypes.data, hsh.ctypes.data,
+                                      toks.ctypes.data, base.ctypes.data, ids.ctypes.data))
+        return {"nodes": nodes, "hash": hsh, "tokens": toks[:nt], "seq_base": base[:nq], "seq_ids": ids[:nq]}
+
+
+class SuffixCache:
+    """Same surface as the reference class (suffix_cache.py:57-222) + `speculate_batch`."""
+
+    def __init__(self, max_depth: int = 64):
+        self._max_depth = max_depth
+        h = N.lib().aic_sc_create(int(max_depth))
+        if not h:
+            raise ValueError(N.lib().aic_last_error().decode())
+        self._h = ctypes.c_void_p(h)
+        self._keys = {}        # req_id -> int64 key handed to the native side (never reused)
+        self._prompt_ids = {}  # insertion-ordered set of req_ids with a cached prompt
+        self._next_key = 0
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().aic_sc_destroy(self._h)
+            self._h = None
+
+    def _key(self, req_id: Hashable) -> int:
+        k = self._keys.get(req_id)
+        if k is None:
+            k = self._next_key
+            self._next_key += 1
+            self._keys[req_id] = k
+        return k
+
+    @property
+    def max_depth(self) -> int:
+        return self._max_depth
+
+    def has_cached_prompt(self, req_id: Hashable) -> bool:
+        return req_id in self._prompt_ids
+
+    def cached_prompt_ids(self) -> List[Hashable]:
+        return list(self._prompt_ids.keys())
+
+    def cache_prompt(self, req_id: Hashable, prompt_token_ids: Sequence[int]):
+        if req_id in self._prompt_ids:
+            raise ValueError(f"Prompt already exists for request '{req_id}'")
+        a = _i32(prompt_token_ids)
+        N.check(N.lib().aic_sc_cache_prompt(self._h, self._key(req_id), a.ctypes.data, a.size))
+        self._prompt_ids[req_id] = True
+
+    def cache_prompts(self, req_ids: Sequence[Hashable], prompts: Sequence[Sequence[int]], n_threads: int = 8):
+        """Several prompts at once; the independent prompt trees are built on host threads."""
+        for r in req_ids:
+            if r in self._prompt_ids:
+                raise ValueError(f"Prompt already exists for request '{r}'")
+        arrs = [_i32(p) for p in prompts]
+        keys = np.asarray([self._key(r) for r in req_ids], np.int64)
+        lens = np.asarray([a.size for a in arrs], np.int32)
+        flat = np.concatenate(arrs) if arrs else np.zeros(0, np.int32)
+        N.check(N.lib().aic_sc_cache_prompts(self._h, len(arrs), keys.ctypes.data, flat.ctypes.data,
+                                             lens.ctypes.data, int(n_threads)))
+        for r in req_ids:
+            self._prompt_ids[r] = True
+
+    def evict_prompt(self, req_id: Hashable):
+        if req_id not in self._prompt_ids:
+            raise ValueError(f"Prompt does not exist for request '{req_id}'")
+        N.check(N.lib().aic_sc_evict_prompt(self._h, self._key(req_id)))
+        del self._prompt_ids[req_id]
+
+    def update_response(self, req_id: Hashable, token_ids: Union[int, Sequence[int]]):
+        a = _i32([token_ids] if isinstance(token_ids, (int, np.integer)) else token_ids)
+        N.check(N.lib().aic_sc_update_response(self._h, self._key(req_id), a.ctypes.data, a.size))
+
+    def speculate(self, req_id: Hashable, pattern: Sequence[int], max_spec_tokens: Optional[int] = None,
+                  max_spec_factor: float = 1.0, max_spec_offset: float = 0.0, min_token_prob: float = 0.1,
+                  use_tree_spec: bool = False, use_cached_prompt: bool = True) -> SuffixSpecResult:
+        if use_cached_prompt and req_id not in self._prompt_ids:
+            raise ValueError(f"Prompt does not exist for request '{req_id}'")
+        if len(pattern) == 0:
+            raise ValueError("Pattern must not be empty")
+        if max_spec_tokens is None:
+            max_spec_tokens = self.max_depth
+        if use_tree_spec:
+            return self._speculate_tree_mode(req_id, pattern, max_spec_tokens, max_spec_factor, max_spec_offset,
+                                             min_token_prob, use_cached_prompt)
+        return self.speculate_batch([req_id], [pattern], [max_spec_tokens], [max_spec_factor], [max_spec_offset],
+                                    [min_token_prob], [use_cached_prompt])[0]
+
+    def _speculate_tree_mode(self, req_id, pattern, max_spec_tokens, factor, offset, min_prob, use_prompt):
+        # tree candidates are an offline-simulator feature of the reference; evaluated by the host trees
+        pattern = list(pattern)[-self._max_depth:]
+        result = SuffixSpecResult()
+        if use_prompt:
+            h = N.lib().aic_sc_prompt_tree(self._h, self._key(req_id))
+            result = SuffixTree(self._max_depth, _handle=h, _owner=self).speculate(
+                pattern, max_spec_tokens, factor, offset, min_prob, True)
+        g = SuffixTree(self._max_depth, _handle=N.lib().aic_sc_global_tree(self._h), _owner=self).speculate(
+            pattern, max_spec_tokens, factor, offset, min_prob, True)
+        return g if g.score > result.score else result
+
+    def speculate_batch(self, req_ids: Sequence[Hashable], patterns: Sequence[Sequence[int]],
+                        max_spec_tokens: Sequence[int], max_spec_factor: Sequence[float],
+                        max_spec_offset: Sequence[float], min_token_prob: Sequence[float],
+                        use_cached_prompt: Sequence[bool]) -> List[SuffixSpecResult]:
+        """All requests of one engine step in one device round trip (path candidates)."""
+        n = len(req_ids)
+        if n == 0:
+            return []
+        for r, p, up in zip(req_ids, patterns, use_cached_prompt):
+            if up and r not in self._prompt_ids:
+                raise ValueError(f"Prompt does not exist for request '{r}'")
+            if len(p) == 0:
+                raise ValueError("Pattern must not be empty")
+        arrs = [_i32(p)[-self._max_depth:] for p in patterns]
+        flat = np.concatenate(arrs)
+        lens = np.asarray([a.size for a in arrs], np.int32)
+        keys = np.asarray([self._key(r) for r in req_ids], np.int64)
+        mst = np.asarray(max_spec_tokens, np.int32)
+        fac = np.asarray(max_spec_factor, np.float32)
+        off = np.asarray(max_spec_offset, np.float32)
+        mpr = np.asarray(min_token_prob, np.float32)
+        upr = np.asarray([1 if u else 0 for u in use_cached_prompt], np.int32)
+        cap = max(1, min(int(mst.max()), self._max_depth))
+        o_tok = np.zeros((n, cap), np.int32)
+        o_prb = np.zeros((n, cap), np.float32)
+        o_n = np.zeros(n, np.int32)
+        o_sc = np.zeros(n, np.float32)
+        o_ml = np.zeros(n, np.int32)
+        N.check(N.lib().aic_sc_speculate_batch(
+            self._h, n, keys.ctypes.data, flat.ctypes.data, lens.ctypes.data, mst.ctypes.data, fac.ctypes.data,
+            off.ctypes.data, mpr.ctypes.data, upr.ctypes.data, cap, o_tok.ctypes.data, o_prb.ctypes.data,
+            o_n.ctypes.data, o_sc.ctypes.data, o_ml.ctypes.data, _stream()))
+        out = []
+        for i in range(n):
+            k = int(o_n[i])
+            out.append(SuffixSpecResult(o_tok[i, :k].tolist(), list(range(-1, k - 1)),
+                                        [float(x) for x in o_prb[i, :k]], float(o_sc[i]), int(o_ml[i])))
+        return out
+
+    def last_stats(self) -> dict:
+        us = ctypes.c_float(0)
+        mb = ctypes.c_int64(0)
+        nn = ctypes.c_int64(0)
+        N.check(N.lib().aic_sc_last_stats(self._h, ctypes.byref(us), ctypes.byref(mb), ctypes.byref(nn)))
+        return {"match_us": float(us.value), "mirrored_bytes": int(mb.value), "n_nodes": int(nn.value)}
+
+    # test helpers
+    def _global_tree(self) -> SuffixTree:
+        return SuffixTree(self._max_depth, _handle=N.lib().aic_sc_global_tree(self._h), _owner=self)
+
+    def _prompt_tree(self, req_id) -> SuffixTree:
+        return SuffixTree(self._max_depth, _handle=N.lib().aic_sc_prompt_tree(self._h, self._key(req_id)), _owner=self)

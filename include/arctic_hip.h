@@ -1,0 +1,274 @@
+/*
+ * arctic_hip.h — C ABI of libarctic_hip.so, the MI355X (gfx950) native library behind the
+ * arctic_inference plugin surface for the speculative-decode + Ulysses hot path.
+ *
+ * One shared library replaces both native extensions of the reference:
+ *   csrc/suffix_cache  (pybind11 module arctic_inference.common.suffix_cache._C)
+ *   csrc/custom_ops    (TORCH_LIBRARY op arctic_inference::reshape_and_cache_flash_bulk)
+ * and adds the kernels the reference delegates to vLLM / PyTorch on its hot path (draft model,
+ * rejection acceptance, verify attention, Ulysses pack/unpack).
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only, no torch types.  Device pointers are `void*` / typed
+ *     pointers into HBM, host pointers are marked "host".
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *   - every function returns an int status: AIC_OK (0) or a negative AIC_ERR_*; the text of the
+ *     last error on the calling thread is available from aic_last_error().
+ *   - nothing here allocates or synchronises inside a launch function unless its comment says so
+ *     (safe to capture in a hipGraph where noted).
+ *   - there is NO CPU fallback: compute entry points fail with AIC_ERR_NO_DEVICE without a GPU.
+ *
+ * Reference interfaces replaced are cited as file:line under /root/reference.
+ */
+#ifndef ARCTIC_HIP_H_
+#define ARCTIC_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AIC_OK 0
+#define AIC_ERR_INVALID (-1)    /* bad argument / shape (reference: TORCH_CHECK -> RuntimeError) */
+#define AIC_ERR_NO_DEVICE (-2)  /* no HIP device visible */
+#define AIC_ERR_HIP (-3)        /* a HIP runtime call failed; see aic_last_error() */
+#define AIC_ERR_NOT_FOUND (-4)  /* unknown request / handle */
+#define AIC_ERR_EXISTS (-5)     /* duplicate request */
+#define AIC_ERR_UNSUPPORTED (-6)
+
+/* element types of activation / cache buffers */
+#define AIC_DT_F32 0
+#define AIC_DT_F16 1
+#define AIC_DT_BF16 2
+#define AIC_DT_FP8_E4M3 3 /* OCP e4m3fn (gfx950 native), not fnuz */
+#define AIC_DT_FP8_E5M2 4
+
+const char* aic_last_error(void);
+int aic_version(void);
+/* number of visible HIP devices (0 on a CPU-only box); never initialises a context */
+int aic_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * A1/A2  Suffix tree — replaces pybind module `_C` (csrc/suffix_cache/pybind.cc:24-38,
+ *        suffix_tree.h:63-110, suffix_tree.cc:31-274).
+ *
+ * Host side: the online update (append/extend) is an inherently serial pointer walk per token and
+ * stays in C++ on the host, exactly where the reference runs it, but in an index arena that is
+ * mirrored incrementally into HBM (nodes, a (parent,token)->child hash, the token store).
+ * Device side: candidate matching (speculate) is a HIP kernel, one wavefront per
+ * (query, tree, suffix start).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct aic_suffix_tree aic_suffix_tree;
+
+aic_suffix_tree* aic_st_create(int max_depth);                 /* SuffixTree(int) pybind.cc:33 */
+void aic_st_destroy(aic_suffix_tree* t);
+int aic_st_num_seqs(const aic_suffix_tree* t);                 /* num_seqs   pybind.cc:34 */
+int aic_st_append(aic_suffix_tree* t, int seq_id, int token);  /* append     pybind.cc:35 */
+int aic_st_extend(aic_suffix_tree* t, int seq_id, const int32_t* tokens /*host*/, int n); /* :36 */
+
+/* speculate (pybind.cc:37, suffix_tree.cc:135-165).  Path mode (use_tree_spec == 0) runs the HIP
+ * matcher on `stream` and synchronises it before returning; tree mode (simulator-only in the
+ * reference, never used in serving: model_runner.py:734-740) is evaluated by the host tree.
+ * Outputs are host arrays of capacity `cap`; returns the number of tokens written (>= 0) or an
+ * error (< 0). */
+int aic_st_speculate(aic_suffix_tree* t, const int32_t* pattern /*host*/, int n, int max_spec_tokens,
+                     float max_spec_factor, float max_spec_offset, float min_token_prob,
+                     int use_tree_spec, int32_t* out_tokens, int32_t* out_parents, float* out_probs,
+                     int cap, float* out_score, int32_t* out_match_len, void* stream);
+
+/* Debug / test export of the flattened device image from the host mirror (no GPU needed).
+ * Fills counts; when the arrays are non-NULL copies them (caller sizes them from a first call).
+ * nodes: int32[n_nodes][8] = {count,parent,seq_id,start,length,best_child,alive,0}
+ * hash : int32[n_slots][4] = {parent,token,child,state(0 empty,1 full,2 tombstone)}
+ * tokens: int32[n_tokens]; seq_base: int32[n_seq_slots] offset of each sequence in `tokens`
+ * seq_ids: int32[n_seq_slots] the caller-visible seq id of each slot */
+int aic_st_export(aic_suffix_tree* t, int32_t* n_nodes, int32_t* n_slots, int32_t* n_tokens,
+                  int32_t* n_seq_slots, int32_t* nodes, int32_t* hash, int32_t* tokens,
+                  int32_t* seq_base, int32_t* seq_ids);
+/* Verifies the incrementally maintained best_child of every node against a full scan in container
+ * order (the reference's tie rule, suffix_tree.cc:208-214). Returns the number of mismatches. */
+int aic_st_selfcheck(aic_suffix_tree* t);
+
+/* ------------------------------------------------------------------------------------------
+ * A3  SuffixCache core — native side of arctic_inference.common.suffix_cache.SuffixCache
+ *     (common/suffix_cache/suffix_cache.py:57-222): one global tree of responses + one prompt
+ *     tree per live request, batched device speculation for a whole engine step.
+ *     Requests are named by an int64 key chosen by the Python layer.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct aic_suffix_cache aic_suffix_cache;
+
+aic_suffix_cache* aic_sc_create(int max_depth);
+void aic_sc_destroy(aic_suffix_cache* c);
+int aic_sc_has_prompt(const aic_suffix_cache* c, int64_t req);
+/* cache_prompt suffix_cache.py:75-96 (AIC_ERR_EXISTS -> ValueError) */
+int aic_sc_cache_prompt(aic_suffix_cache* c, int64_t req, const int32_t* tokens /*host*/, int n);
+/* builds several prompt trees concurrently on host threads (independent trees) */
+int aic_sc_cache_prompts(aic_suffix_cache* c, int n_req, const int64_t* reqs, const int32_t* tokens /*host, concatenated*/,
+                         const int32_t* lens, int n_threads);
+/* evict_prompt suffix_cache.py:98-111 (AIC_ERR_NOT_FOUND -> ValueError) */
+int aic_sc_evict_prompt(aic_suffix_cache* c, int64_t req);
+/* update_response suffix_cache.py:118-149; seq ids are dense in first-seen order (:113-116) */
+int aic_sc_update_response(aic_suffix_cache* c, int64_t req, const int32_t* tokens /*host*/, int n);
+
+/* speculate for a batch of requests (suffix_cache.py:151-222 applied per request; the call
+ * pattern of model_runner.py:680-744).  All arrays are host arrays of length n_query unless
+ * noted.  patterns: concatenated int32, pattern_lens[i] tokens each (only the last max_depth of
+ * each are used, :197-198).  use_prompt[i] != 0 -> also search the request's prompt tree
+ * (AIC_ERR_NOT_FOUND if it has none).  Outputs: out_tokens/out_probs [n_query][cap] row-major,
+ * out_n / out_match_len / out_score [n_query].  Pending tree updates are mirrored to HBM, the
+ * matcher runs on `stream`, results are copied back and the stream is synchronised. */
+int aic_sc_speculate_batch(aic_suffix_cache* c, int n_query, const int64_t* reqs, const int32_t* patterns,
+                           const int32_t* pattern_lens, const int32_t* max_spec_tokens,
+                           const float* max_spec_factor, const float* max_spec_offset,
+                           const float* min_token_prob, const int32_t* use_prompt, int cap,
+                           int32_t* out_tokens, float* out_probs, int32_t* out_n, float* out_score,
+                           int32_t* out_match_len, void* stream);
+/* device time of the last aic_sc_speculate_batch matcher launch pair in microseconds (HIP events
+ * on the caller's stream), and the number of bytes mirrored host->device for it */
+int aic_sc_last_stats(const aic_suffix_cache* c, float* match_us, int64_t* mirrored_bytes, int64_t* n_nodes_total);
+aic_suffix_tree* aic_sc_global_tree(aic_suffix_cache* c);
+aic_suffix_tree* aic_sc_prompt_tree(aic_suffix_cache* c, int64_t req);
+
+/* ------------------------------------------------------------------------------------------
+ * A16  Bulk paged-KV write — replaces torch.ops.arctic_inference.reshape_and_cache_flash_bulk
+ *      (csrc/custom_ops/torch_bindings.cpp:5-18, kernels.cu:12-155, py_custom_ops.py:40-54).
+ *      cache[layer][slot / block_size][slot % block_size][h][d] = cvt(src[token][layer*H*D + h*D + d])
+ *      for K and V of all layers in ONE launch; slot < 0 tokens are skipped (kernels.cu:33-35).
+ *      Pointer tables are HOST arrays of device pointers (length num_layers) and are passed to the
+ *      kernel by value: no per-call H2D copy (the reference does four, kernels.cu:116-146).
+ *      kv_dtype: same as src_dtype ("auto") or AIC_DT_FP8_E4M3 / AIC_DT_FP8_E5M2 with x/scale and
+ *      saturate-to-finite conversion (quant_utils.cuh:455-489); scale tables may be NULL for auto.
+ *      Strides are in elements.  Graph-capture safe.
+ * ---------------------------------------------------------------------------------------- */
+int aic_reshape_and_cache_flash_bulk(const void* keys, const void* values, void* const* key_cache_ptrs /*host*/,
+                                     void* const* value_cache_ptrs /*host*/, const int64_t* slot_mapping,
+                                     int num_tokens, int num_layers, int num_heads, int head_size,
+                                     int block_size, int64_t block_stride, int64_t key_stride,
+                                     int64_t value_stride, int src_dtype, int kv_dtype,
+                                     const float* const* k_scale_ptrs /*host*/, const float* const* v_scale_ptrs /*host*/,
+                                     void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A6  Rejection acceptance — replaces the call into vllm.v1.sample.rejection_sampler
+ *     (model_runner.py:405-411, parsed at :456-459) for draft_probs == None.
+ *     target_logits: [num_draft_total, vocab] (AIC_DT_BF16 / F16 / F32), row stride in elements.
+ *     draft_token_ids int32 [num_draft_total]; cu_num_draft int32 [B] inclusive prefix sums;
+ *     bonus_token_ids int32 [B]; out int32 [B][max_spec_len+1] (filled with -1 first).
+ *     Greedy rows: out[i][p] = argmax(target_logits[row]) until the first draft != argmax; bonus
+ *     token at position n_i if nothing was rejected.  Row arg-max ties -> lowest index.
+ *     Also emits, per request, what the next proposer step needs (arctic_proposer.py:133-147):
+ *     num_accepted[i] (tokens written), last_token[i], hidden_index[i] = (gen_len_i - 1) +
+ *     sum_{j<i}(n_j + 1).  Any of those three may be NULL.
+ *     workspace: >= aic_rejection_workspace_bytes(num_draft_total, vocab) bytes of HBM.
+ * ---------------------------------------------------------------------------------------- */
+size_t aic_rejection_workspace_bytes(int num_draft_total, int vocab);
+int aic_rejection_greedy(const void* target_logits, int logits_dtype, int64_t row_stride, int vocab,
+                         const int32_t* draft_token_ids, const int32_t* cu_num_draft,
+                         const int32_t* bonus_token_ids, int batch, int num_draft_total, int max_spec_len,
+                         int32_t* out_token_ids, int32_t* num_accepted, int32_t* last_token,
+                         int32_t* hidden_index, void* workspace, void* stream);
+/* Random rows (temperature > 0), draft_probs == None: accept draft iff softmax(logits/T)[draft] >= u,
+ * else emit the recovered token argmax_v(p_v / q_v) with p[draft] := 0, q ~ Exp(1).
+ * uniform: f64 [num_draft_total]; exp_noise: f32 [B][vocab]; temperature f32 [B]
+ * (<= 0 means greedy row).  is_greedy rows use the greedy rule. */
+int aic_rejection_random(const void* target_logits, int logits_dtype, int64_t row_stride, int vocab,
+                         const int32_t* draft_token_ids, const int32_t* cu_num_draft,
+                         const int32_t* bonus_token_ids, const float* temperature, const double* uniform,
+                         const float* exp_noise, int batch, int num_draft_total, int max_spec_len,
+                         int32_t* out_token_ids, int32_t* num_accepted, int32_t* last_token,
+                         int32_t* hidden_index, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A7-A11  Arctic LSTM speculator (sum_lstm) — replaces ArcticLSTMSpeculator.generate_proposals /
+ *     generate_token_ids / generate_states and LogitsProcessorOpt + arg-max
+ *     (vllm/spec_dec/arctic_speculator.py:648-866, logits_processor_opt.py:83-107,
+ *     fp8.py:276-308, arctic_proposer.py:113-166).
+ *     Weights stay owned by the caller (torch tensors); the handle stores pointers + scratch.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct aic_lstm aic_lstm;
+
+typedef struct aic_lstm_config {
+  int32_t vocab_size;        /* rows of the (local) LM head shard */
+  int32_t vocab_offset;      /* global index of local row 0 (tp_rank * shard, vocab_parallel_embedding.py:32-35) */
+  int32_t input_hidden_dim;  /* H */
+  int32_t inner_dim;         /* Ds == proj_dim == emb_dim (arctic_speculator.py:667-688) */
+  int32_t n_predict;         /* used for state_weight = 0.5^(0.5/n_predict) (:575-577) */
+  int32_t scale_input;       /* ln0 + 1/sqrt(2) on head 0 (:656-657) */
+  int32_t max_batch;         /* scratch sizing (padded batch) */
+  int32_t head_fp8_max_batch;/* use the fp8 LM head when padded batch <= this (32, :726-728); 0 = never */
+} aic_lstm_config;
+
+typedef struct aic_lstm_weights {
+  const void* forget_emb;   /* bf16 [V_full, Ds]   replicated embedding (:546-547) */
+  const void* proj0;        /* bf16 [4Ds, H]       projs.0.weight = f|i|o|c rows (:874-891) */
+  const void* proj1;        /* bf16 [4Ds, Ds]      projs.1.weight */
+  const void* cell_ln_w;    /* bf16 [Ds] */
+  const void* cell_ln_b;    /* bf16 [Ds] */
+  const void* state_ln_w;   /* bf16 [Ds] */
+  const void* state_ln_b;   /* bf16 [Ds] */
+  const void* head;         /* bf16 [V_local, Ds]  tied LM head */
+  const void* head_fp8;     /* e4m3fn [V_local, Ds] per-tensor quantised copy (fp8.py:207-223) or NULL */
+  float head_fp8_scale;     /* weight_scale of head_fp8 */
+} aic_lstm_weights;
+
+int aic_lstm_create(const aic_lstm_config* cfg, const aic_lstm_weights* w, aic_lstm** out);
+void aic_lstm_destroy(aic_lstm* m);
+/* per-tensor e4m3fn quantisation of a bf16 matrix: scale = amax/448, q = sat(x/scale)
+ * (ops.scaled_fp8_quant with scale=None, fp8.py:207-210).  scale_out: device f32[1]. */
+int aic_quantize_fp8_per_tensor(const void* src_bf16, void* dst_fp8, float* scale_out, int64_t n, void* stream);
+/* padding_size(): arctic_speculator.py:39-44 */
+int aic_lstm_padding_size(int batch);
+/* One call = the whole k-head draft loop on `stream` (no host sync, graph-capture safe):
+ *   hidden: bf16 [*, H]; row i of the batch uses hidden[hidden_index[i]] (hidden_index NULL -> i)
+ *   last_tokens: int32 [B];  out_tokens: int64 [B][k] GLOBAL token ids (local arg-max + vocab_offset)
+ *   out_vals: f32 [B][k] bf16-rounded max logit per head (for the TP arg-max exchange, :733-744), may be NULL */
+int aic_lstm_propose(aic_lstm* m, const void* hidden, const int32_t* hidden_index, const int32_t* last_tokens,
+                     int batch, int num_predict_tokens, int64_t* out_tokens, float* out_vals, void* stream);
+/* single-head entry points for the vocab-parallel (TP/SP > 1) loop, where an all-gather of
+ * (value, index) sits between heads.  State lives in the handle. */
+int aic_lstm_begin(aic_lstm* m, const void* hidden, const int32_t* hidden_index, int batch, void* stream);
+int aic_lstm_head(aic_lstm* m, int head_index, const int32_t* last_tokens /* [B] global ids */, int batch,
+                  int64_t* out_tokens /* [B] */, float* out_vals /* [B] */, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A5  Multi-token verify paged attention — what `self._orig_forward(q_, k_, v_)` reaches through
+ *     vLLM's attention backend on the reference path (ulysses.py:510).  Causal var-len attention
+ *     of q_len_i = 1 + n_draft_i query tokens per request over that request's paged KV
+ *     (FlashAttention cache layout [num_blocks, block_size, Hkv, D], llama_swiftkv.py:617), new
+ *     K/V already written.  Linear chains only (model_runner.py:734-740): the "tree" mask is
+ *     causal within the chunk.
+ *       q/out: bf16 [T][Hq][D] (token stride q_stride / out_stride elements)
+ *       block_table int32 [B][max_blocks]; seq_lens int32 [B] (context incl. the new tokens);
+ *       query_start_loc int32 [B+1].  head_size 64 or 128.  kv_dtype BF16 or FP8_E4M3 (+ scales).
+ *     workspace >= aic_verify_attention_workspace_bytes(...).  Graph-capture safe.
+ * ---------------------------------------------------------------------------------------- */
+size_t aic_verify_attention_workspace_bytes(int num_tokens, int num_q_heads, int head_size, int num_splits_max);
+int aic_verify_attention(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
+                         int64_t block_stride, int kv_dtype, const float* k_scale, const float* v_scale,
+                         const int32_t* block_table, int max_blocks_per_seq, const int32_t* seq_lens,
+                         const int32_t* query_start_loc, int batch, int num_tokens, int max_q_len,
+                         int num_q_heads, int num_kv_heads, int head_size, int block_size, float sm_scale,
+                         void* out, int64_t out_stride, void* workspace, size_t workspace_bytes,
+                         int max_seq_len, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A12  Ulysses head/sequence repartition — the copies around the two all-to-alls of
+ *      UlyssesAttentionPatch.forward (ulysses.py:493-507, :513-517).  The collectives
+ *      themselves stay torch.distributed (RCCL) calls in the Python layer.
+ *      pack:   q [n][SP*hq*D], k,v [n][SP*hkv*D]  ->  send [SP][n][(hq+2hkv)*D]
+ *      split:  recv [SP*n][(hq+2hkv)*D] -> q_ [SP*n][hq*D], k_, v_ [SP*n][hkv*D]   (contiguous outputs)
+ *      unpack: recv [SP][n][hq*D] -> out [n][SP*hq*D]
+ *      bf16/f16 (2-byte elements).  Graph-capture safe.
+ * ---------------------------------------------------------------------------------------- */
+int aic_ulysses_pack_qkv(const void* q, const void* k, const void* v, int64_t q_stride, int64_t k_stride,
+                         int64_t v_stride, void* send, int n_local, int sp, int q_width, int kv_width, void* stream);
+int aic_ulysses_split_qkv(const void* recv, void* q, void* k, void* v, int64_t rows, int q_width, int kv_width,
+                          void* stream);
+int aic_ulysses_unpack_out(const void* recv, void* out, int n_local, int sp, int width, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARCTIC_HIP_H_ */

@@ -1,0 +1,263 @@
+"""ORACLE — test infrastructure only (never imported by the product package).
+
+CPU restatements (torch on the CPU / numpy) of the parts of the hot path that live in Python or in
+third-party code on the reference side.  Each function cites what it follows.  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+PARITY STATUS
+  * lstm_*            : literal restatement of the reference's torch op sequence
+                        (arctic_speculator.py:88-95, :648-751; fp8.py:207-223, :276-308), executed with
+                        torch CPU bf16 tensors so every op rounds where the reference's does.  The
+                        reference module cannot be imported (vLLM absent) and ships no fixture for it:
+                        PARITY UNPINNED against the reference itself; pinned to this restatement.
+  * rejection_*       : vLLM 0.9.2 RejectionSampler semantics for draft_probs=None, recalled
+                        (SURVEY.md §8a A6); no source or fixture under /root/reference: PARITY UNPINNED.
+  * verify_attention  : plain fp32 softmax(QK^T)V with the causal rule of SURVEY §8a A5: PARITY UNPINNED
+                        (tolerance 1e-3 in bf16 per BASELINE.json).
+  * kv_bulk_write     : restates csrc/custom_ops/kernels.cu:29-68; pinned only in interface/shape by the
+                        reference's own (self-comparing) test tests/unit_tests/test_custom_ops.py:56-118.
+  * ulysses_*         : the literal torch expression of ulysses.py:493-517, with a single-process
+                        emulation of all_to_all_single.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+SQRT2 = 2 ** 0.5
+
+
+# ----------------------------------------------------------------------------------------------
+# LSTM speculator (arctic_speculator.py)
+# ----------------------------------------------------------------------------------------------
+def _l2norm(x: torch.Tensor, weight=None, bias=None, eps: float = 1e-6) -> torch.Tensor:
+    """MLPSpeculatorLayerNorm.forward (arctic_speculator.py:88-95), dtype-preserving like the original."""
+    xf = x
+    xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    x = xf.type_as(x)
+    if weight is not None:
+        x = weight * x
+        x = x + bias
+    return x
+
+
+def fp8_quant_per_tensor(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Dynamic per-tensor e4m3fn quantisation (ops.scaled_fp8_quant(x, scale=None), fp8.py:209):
+    scale = max(amax/448, 1/(448*512)); q = sat(x * (1/scale))."""
+    amax = x.abs().max().to(torch.float32)
+    scale = torch.maximum(amax / 448.0, torch.tensor(1.0 / (448.0 * 512.0)))
+    inv = (torch.tensor(1.0, dtype=torch.float32) / scale)
+    q = (x.to(torch.float32) * inv).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return q, scale.reshape(1)
+
+
+def lstm_generate_proposals(w: Dict[str, torch.Tensor], input_ids: torch.Tensor, hidden: torch.Tensor, k: int,
+                            n_predict: int, scale_input: bool = True, fp8_head: bool = False,
+                            return_logits: bool = False):
+    """generate_states + generate_token_ids for method == "sum_lstm", tp_size == 1
+    (arctic_speculator.py:648-751), on CPU bf16.  `w` uses the module's parameter names after the
+    reference loader ran: projs.{0,1}.weight = cat(forget, input, output, cell) (:886-891)."""
+    dt = torch.bfloat16
+    Ds = w["cell_ln.0.weight"].numel()
+    state_weight = 0.5 ** (0.5 / n_predict)
+    emb_weight = math.sqrt((1 - state_weight ** 2) * (Ds / 2))
+    prev = hidden.to(dt).unsqueeze(1)          # b 1 d
+    last = input_ids.long().unsqueeze(1)       # b 1
+    cell = torch.zeros(prev.shape[0], 1, Ds, dtype=dt)
+    head_w = w["head.0.weight"].to(dt)
+    if fp8_head:
+        qw, w_scale = fp8_quant_per_tensor(head_w)      # post-load hook, fp8.py:207-223
+        qw_f = qw.to(torch.float32)
+    gelu = torch.nn.GELU()
+    out, all_logits = [], []
+    for head_index in range(k):
+        if head_index == 0 and scale_input:
+            prev = _l2norm(prev) / SQRT2
+        proj = w["projs.0.weight"] if head_index == 0 else w["projs.1.weight"]
+        z = torch.nn.functional.embedding(last, w["forget_emb.0.weight"].to(dt)).repeat(1, 1, 4)
+        states = torch.nn.functional.linear(prev, proj.to(dt))
+        added = torch.add(states, z, alpha=emb_weight / state_weight)
+        fio, cand = added.split([Ds * 3, Ds], dim=-1)
+        f, i, o = torch.sigmoid(fio).split([Ds, Ds, Ds], dim=-1)
+        cand = gelu(_l2norm(cand, w["cell_ln.0.weight"].to(dt), w["cell_ln.0.bias"].to(dt)))
+        cand = cand * i
+        cell = cell * f
+        cell = cell + cand
+        st = gelu(_l2norm(cell, w["state_ln.0.weight"].to(dt), w["state_ln.0.bias"].to(dt)))
+        state = st * o
+        prev = state
+        flat = state.flatten(0, 1)
+        if fp8_head:
+            qx, x_scale = fp8_quant_per_tensor(flat)    # Fp8LinearOp dynamic activation scale
+            logits = ((qx.to(torch.float32) @ qw_f.t()) * (x_scale * w_scale)).to(dt)
+        else:
+            logits = torch.nn.functional.linear(flat, head_w)
+        last = torch.argmax(logits, dim=-1).reshape(-1, 1)
+        out.append(last)
+        all_logits.append(logits)
+    toks = torch.cat(out, dim=-1)
+    return (toks, all_logits) if return_logits else toks
+
+
+def merge_lstm_checkpoint(ckpt: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """The reference loader's renaming (arctic_speculator.py:874-902) on a plain dict."""
+    w = dict(ckpt)
+    for drop in ("input_emb.0.weight", "cell_emb.0.weight", "output_emb.0.weight"):
+        w.pop(drop, None)
+    for i in (0, 1):
+        w[f"projs.{i}.weight"] = torch.cat([w.pop(f"{g}_proj.{i}.weight") for g in ("forget", "input", "output", "cell")])
+    return w
+
+
+# ----------------------------------------------------------------------------------------------
+# hidden-state pick (arctic_proposer.py:133-147)
+# ----------------------------------------------------------------------------------------------
+def hidden_state_index(sampled_token_ids: np.ndarray, num_draft_tokens: Sequence[int]) -> np.ndarray:
+    valid = sampled_token_ids != -1
+    gen_lens = valid.sum(axis=1)
+    n = np.asarray(num_draft_tokens) + 1
+    return (gen_lens - 1) + np.cumsum(n) - n
+
+
+# ----------------------------------------------------------------------------------------------
+# rejection acceptance (vLLM RejectionSampler, draft_probs=None) — recalled semantics
+# ----------------------------------------------------------------------------------------------
+def rejection_greedy(target_logits: torch.Tensor, draft_token_ids: Sequence[int], num_draft_tokens: Sequence[int],
+                     bonus_token_ids: Sequence[int], max_spec_len: int) -> np.ndarray:
+    B = len(num_draft_tokens)
+    out = np.full((B, max_spec_len + 1), -1, dtype=np.int32)
+    argmax = torch.argmax(target_logits.float(), dim=-1).numpy() if target_logits.numel() else np.zeros(0, np.int64)
+    start = 0
+    for i, n in enumerate(num_draft_tokens):
+        rejected = False
+        for pos in range(n):
+            if not rejected:
+                tgt = int(argmax[start + pos])
+                out[i, pos] = tgt
+                if int(draft_token_ids[start + pos]) != tgt:
+                    rejected = True
+        if not rejected:
+            out[i, n] = int(bonus_token_ids[i])
+        start += n
+    return out
+
+
+def rejection_random(target_logits: torch.Tensor, draft_token_ids: Sequence[int], num_draft_tokens: Sequence[int],
+                     bonus_token_ids: Sequence[int], max_spec_len: int, temperature: Sequence[float],
+                     uniform: np.ndarray, exp_noise: torch.Tensor) -> np.ndarray:
+    """Rows with temperature <= 0 are greedy.  Random rows: x = logits.div_(T) in the logits dtype,
+    p = softmax(x, fp32); accept the draft iff p[draft] >= u; otherwise emit
+    argmax(p / q) with p[draft] := 0, q ~ Exp(1) per request."""
+    B = len(num_draft_tokens)
+    out = np.full((B, max_spec_len + 1), -1, dtype=np.int32)
+    start = 0
+    for i, n in enumerate(num_draft_tokens):
+        rejected = False
+        T = float(temperature[i])
+        for pos in range(n):
+            if rejected:
+                break
+            row = target_logits[start + pos]
+            draft = int(draft_token_ids[start + pos])
+            if T <= 0:
+                tok = int(torch.argmax(row.float()))
+                out[i, pos] = tok
+                rejected = draft != tok
+            else:
+                x = (row / T).to(row.dtype)
+                p = torch.softmax(x.float(), dim=-1)
+                if float(p[draft]) >= float(uniform[start + pos]):
+                    out[i, pos] = draft
+                else:
+                    p2 = p.clone()
+                    p2[draft] = 0.0
+                    out[i, pos] = int(torch.argmax(p2 / exp_noise[i].float()))
+                    rejected = True
+        if not rejected:
+            out[i, n] = int(bonus_token_ids[i])
+        start += n
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# verify attention — fp32 reference
+# ----------------------------------------------------------------------------------------------
+def verify_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_table: torch.Tensor,
+                     seq_lens: Sequence[int], query_start_loc: Sequence[int], sm_scale: float) -> torch.Tensor:
+    """q [T,Hq,D]; caches [num_blocks, block_size, Hkv, D]; returns fp32 [T,Hq,D]."""
+    T, Hq, D = q.shape
+    _, bs, Hkv, _ = k_cache.shape
+    G = Hq // Hkv
+    out = torch.zeros(T, Hq, D, dtype=torch.float32)
+    for i, ctx in enumerate(seq_lens):
+        q0, q1 = int(query_start_loc[i]), int(query_start_loc[i + 1])
+        qlen = q1 - q0
+        if qlen == 0:
+            continue
+        nblk = (ctx + bs - 1) // bs
+        blocks = block_table[i, :nblk].long()
+        K = k_cache[blocks].reshape(-1, Hkv, D)[:ctx].float()  # [ctx, Hkv, D]
+        V = v_cache[blocks].reshape(-1, Hkv, D)[:ctx].float()
+        Q = q[q0:q1].float()                                     # [qlen, Hq, D]
+        Kh = K.repeat_interleave(G, dim=1)                       # [ctx, Hq, D]
+        Vh = V.repeat_interleave(G, dim=1)
+        s = torch.einsum("qhd,khd->hqk", Q, Kh) * sm_scale
+        pos = torch.arange(qlen).unsqueeze(1) + (ctx - qlen)
+        mask = torch.arange(ctx).unsqueeze(0) <= pos             # [qlen, ctx]
+        s = s.masked_fill(~mask.unsqueeze(0), float("-inf"))
+        p = torch.softmax(s, dim=-1)
+        out[q0:q1] = torch.einsum("hqk,khd->qhd", p, Vh)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# bulk KV write (csrc/custom_ops/kernels.cu:29-68)
+# ----------------------------------------------------------------------------------------------
+def fp8_sat(x: torch.Tensor, kind: str) -> torch.Tensor:
+    """x (fp32) -> OCP fp8 with saturation to the largest finite value (CUDA __NV_SATFINITE)."""
+    if kind == "e4m3":
+        return x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return x.clamp(-57344.0, 57344.0).to(torch.float8_e5m2)
+
+
+def kv_bulk_write(keys, values, key_caches, value_caches, slot_mapping, kv_cache_dtype, k_scales, v_scales,
+                  num_heads, head_size) -> None:
+    n = num_heads * head_size
+    bs = key_caches[0].shape[1]
+    for layer in range(len(key_caches)):
+        for t in range(slot_mapping.numel()):
+            slot = int(slot_mapping[t])
+            if slot < 0:
+                continue
+            b, o = slot // bs, slot % bs
+            ksrc = keys[t, layer * n:(layer + 1) * n].reshape(num_heads, head_size)
+            vsrc = values[t, layer * n:(layer + 1) * n].reshape(num_heads, head_size)
+            if kv_cache_dtype == "auto":
+                key_caches[layer][b, o] = ksrc
+                value_caches[layer][b, o] = vsrc
+            else:
+                kind = "e5m2" if kv_cache_dtype == "fp8_e5m2" else "e4m3"
+                key_caches[layer][b, o] = fp8_sat(ksrc.float() / k_scales[layer].float(), kind)
+                value_caches[layer][b, o] = fp8_sat(vsrc.float() / v_scales[layer].float(), kind)
+
+
+# ----------------------------------------------------------------------------------------------
+# Ulysses pack / unpack (ulysses.py:493-517) with a single-process all_to_all_single emulation
+# ----------------------------------------------------------------------------------------------
+def ulysses_pack(q, k, v, sp, hq, hkv, D):
+    return (torch.cat((q.view(-1, sp, hq * D), k.view(-1, sp, hkv * D), v.view(-1, sp, hkv * D)), dim=-1)
+            .transpose(0, 1).reshape(-1, (hq + 2 * hkv) * D))
+
+
+def ulysses_unpack(c, sp, hq, D):
+    return c.view(sp, -1, hq * D).transpose(0, 1).reshape(-1, hq * sp * D)
+
+
+def all_to_all_single_emulated(per_rank_inputs: List[torch.Tensor]) -> List[torch.Tensor]:
+    """Equal-split all_to_all_single over len(per_rank_inputs) ranks: rank r receives chunk r of everyone."""
+    sp = len(per_rank_inputs)
+    chunks = [t.chunk(sp, dim=0) for t in per_rank_inputs]
+    return [torch.cat([chunks[src][dst] for src in range(sp)], dim=0) for dst in range(sp)]

@@ -1,0 +1,137 @@
+"""GPU parity: the HIP suffix matcher (through the C ABI) against the golden vectors produced by the
+real reference, and against the oracle on seeded replays up to the BASELINE size."""
+import random
+
+import pytest
+
+import golden_utils as gu
+from arcticinference_amd.suffix_cache import SuffixCache, SuffixTree
+from arcticinference_amd.workload import TokenSource
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["suffix_traces.json", "suffix_ties.json", "suffix_clamps.json",
+                                  "suffix_treespec.json"])
+def test_device_tree_matches_golden(name):
+    total = 0
+    for case in gu.load(name):
+        total += gu.replay_tree_case(case, SuffixTree)
+    assert total > 100
+
+
+def test_device_cache_matches_golden():
+    total = sum(gu.replay_cache_case(c, SuffixCache) for c in gu.load("suffix_cache.json"))
+    assert total > 100
+
+
+def test_device_cache_errors_and_edges():
+    c = SuffixCache(8)
+    c.cache_prompt("a", [1, 2, 3])
+    with pytest.raises(ValueError):
+        c.speculate("zzz", [1])
+    with pytest.raises(ValueError):
+        c.speculate("a", [])
+    # nothing cached in the global tree yet: empty result, not an error
+    r = c.speculate("b", [1, 2], use_cached_prompt=False)
+    assert r.token_ids == [] and r.score == 0.0 and r.match_len == 0
+    r = c.speculate("a", [9, 9, 1, 2], max_spec_tokens=4)
+    assert r.token_ids == [3] and r.match_len == 2
+    # max_spec_tokens == 0 and patterns longer than max_depth
+    assert c.speculate("a", [1, 2], max_spec_tokens=0).token_ids == []
+    assert c.speculate("a", list(range(100, 130)) + [1, 2], max_spec_tokens=4).token_ids == [3]
+
+
+def _replay(cache, cfg, batched):
+    """simulator.suffix_decode-style replay (oracle/gen_golden.py:replay) on the device path."""
+    import hashlib
+    import struct
+    src = TokenSource(seed=cfg["seed"])
+    n_req = cfg["n_req"]
+    reqs = [src.request(r, cfg["prompt_len"], cfg["gen_len"]) for r in range(n_req)]
+    prompts = [[int(x) for x in p] for p, _ in reqs]
+    gts = [[int(x) for x in g] for _, g in reqs]
+    out = []
+    if not batched:
+        order = [[r] for r in range(n_req)]
+    else:
+        order = None
+    # sequential per request reproduces the golden digests exactly (the global tree evolves in the same order)
+    for r in range(n_req):
+        cache.cache_prompt(r, prompts[r])
+        h = hashlib.sha256()
+        resp, steps, acc, spec = [], 0, 0, 0
+        gt = gts[r]
+        while len(resp) < len(gt):
+            text = (prompts[r] + resp)[-cache.max_depth:]
+            res = cache.speculate(r, text, max_spec_tokens=cfg["max_spec_tokens"], max_spec_factor=cfg["factor"],
+                                  max_spec_offset=cfg["offset"], min_token_prob=cfg["min_token_prob"])
+            h.update(struct.pack("<i", res.match_len))
+            h.update(struct.pack("<f", res.score))
+            h.update(struct.pack(f"<{len(res.token_ids)}i", *res.token_ids))
+            a = 0
+            for tok in res.token_ids:
+                if len(resp) + a < len(gt) and gt[len(resp) + a] == tok:
+                    a += 1
+                else:
+                    break
+            new = gt[len(resp):len(resp) + a]
+            resp.extend(new)
+            if len(resp) < len(gt):
+                new = new + [gt[len(resp)]]
+                resp.append(gt[len(resp)])
+            cache.update_response(r, new)
+            steps += 1
+            acc += a
+            spec += len(res.token_ids)
+        cache.evict_prompt(r)
+        out.append({"steps": steps, "accepted": acc, "speculated": spec, "sha256": h.hexdigest()})
+    return out
+
+
+def test_device_replay_small_digest():
+    want = gu.load("suffix_replay.json")[0]
+    got = _replay(SuffixCache(64), want["config"], batched=False)
+    assert got == want["per_request"]
+
+
+def test_device_replay_full_size_digest():
+    """BASELINE size: 64 requests x (4096 prompt + 256 generated), digests from the real reference."""
+    want = gu.load("suffix_replay.json")[1]
+    got = _replay(SuffixCache(64), want["config"], batched=False)
+    assert got == want["per_request"]
+    assert sum(g["accepted"] for g in got) == want["sum_accept"]
+
+
+def test_batched_step_equals_oracle():
+    """The engine-step pattern: B live requests, one speculate_batch per step; vs the oracle cache."""
+    from oracle.suffix_oracle import OracleSuffixCache
+    src = TokenSource(seed=5)
+    B, PL, GL = 16, 512, 48
+    dev, orc = SuffixCache(64), OracleSuffixCache(64)
+    data = [src.request(r, PL, GL) for r in range(B)]
+    rows = [[int(x) for x in p] for p, _ in data]
+    gts = [[int(x) for x in g] for _, g in data]
+    dev.cache_prompts(list(range(B)), rows, n_threads=4)
+    for r in range(B):
+        orc.cache_prompt(r, rows[r])
+    done = [0] * B
+    rng = random.Random(0)
+    for step in range(40):
+        live = [r for r in range(B) if done[r] < GL]
+        if not live:
+            break
+        for r in live:
+            n_new = min(rng.randint(1, 4), GL - done[r])
+            new = gts[r][done[r]:done[r] + n_new]
+            dev.update_response(r, new)
+            orc.update_response(r, new)
+            rows[r].extend(new)
+            done[r] += n_new
+        pats = [rows[r][-64:] for r in live]
+        res = dev.speculate_batch(live, pats, [32] * len(live), [1.0] * len(live), [0.0] * len(live),
+                                  [0.1] * len(live), [True] * len(live))
+        for r, p, got in zip(live, pats, res):
+            want = orc.speculate(r, p, max_spec_tokens=32)
+            gu.assert_cand(got, gu.cand_dict(want), ctx=f"step {step} req {r}")
+    assert dev._global_tree().selfcheck() == 0

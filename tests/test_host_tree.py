@@ -1,0 +1,95 @@
+"""CPU: the product's host suffix tree (arcticinference_amd/csrc/suffix_host.hpp) and the HBM image
+it mirrors, checked against the golden vectors from the real reference.  No compute call is made on
+the library (there is no GPU here): the image is exported and walked by tests/flat_matcher.py."""
+import random
+
+import pytest
+
+import flat_matcher
+import golden_utils as gu
+from arcticinference_amd.suffix_cache import SuffixCache, SuffixTree
+
+
+class _ImgTree:
+    def __init__(self, depth):
+        self.t = SuffixTree(depth)
+        self.depth = depth
+
+    def extend(self, seq, toks):
+        self.t.extend(seq, toks)
+
+    def speculate(self, pat, mst, factor, offset, mp, tree):
+        if tree:  # tree mode is a host feature of the library
+            return self.t.speculate(pat, mst, factor, offset, mp, True)
+        assert self.t.selfcheck() == 0
+        return flat_matcher.speculate(self.t.export(), list(pat), mst, factor, offset, mp, self.depth)
+
+
+@pytest.mark.parametrize("name", ["suffix_traces.json", "suffix_ties.json", "suffix_treespec.json"])
+def test_host_image_matches_golden(name):
+    total = 0
+    for case in gu.load(name):
+        total += gu.replay_tree_case(case, _ImgTree)
+    assert total > 100
+
+
+def test_host_image_clamps_subset():
+    case = gu.load("suffix_clamps.json")[0]
+    case = dict(case, events=case["events"][:2] + case["events"][2::7])
+    assert gu.replay_tree_case(case, _ImgTree) > 100
+
+
+def test_best_child_bookkeeping_fuzz():
+    """NodeRec.best must always equal the reference's container-order scan (selfcheck)."""
+    for trial in range(40):
+        rng = random.Random(trial)
+        t = SuffixTree(rng.choice([3, 5, 8, 64]))
+        vocab = rng.choice([2, 3, 6, 30, 3000])
+        for step in range(rng.randint(200, 1500)):
+            t.append(rng.randrange(4), rng.randrange(vocab))
+            if step % 97 == 0:
+                assert t.selfcheck() == 0
+        assert t.selfcheck() == 0
+
+
+def test_cache_surface_and_errors():
+    c = SuffixCache(8)
+    assert c.max_depth == 8
+    c.cache_prompt("a", [1, 2, 3])
+    assert c.has_cached_prompt("a") and c.cached_prompt_ids() == ["a"]
+    with pytest.raises(ValueError):
+        c.cache_prompt("a", [1])
+    with pytest.raises(ValueError):
+        c.evict_prompt("b")
+    with pytest.raises(ValueError):
+        c.speculate("b", [1])
+    with pytest.raises(ValueError):
+        c.speculate("a", [])
+    c.update_response("a", 4)
+    c.update_response("b", [1, 2, 3])
+    assert c._global_tree().num_seqs() == 2
+    assert c._prompt_tree("a").export()["tokens"][:4].tolist() == [1, 2, 3, 4]
+    c.evict_prompt("a")
+    assert not c.has_cached_prompt("a")
+    c.cache_prompts(["x", "y"], [[1, 2, 3, 1, 2], [5, 5, 5]], n_threads=2)
+    assert c.cached_prompt_ids() == ["x", "y"]
+    assert c._prompt_tree("y").selfcheck() == 0
+
+
+def test_cache_tree_mode_matches_oracle():
+    from oracle.suffix_oracle import OracleSuffixCache
+    rng = random.Random(5)
+    a, b = SuffixCache(8), OracleSuffixCache(8)
+    for c in (a, b):
+        c.cache_prompt(0, [1, 2, 3, 1, 2, 4, 1, 2, 3])
+    hist = []
+    for step in range(200):
+        tok = rng.randrange(1, 5)
+        hist.append(tok)
+        for c in (a, b):
+            c.update_response(0, tok)
+        if step % 5 == 0:
+            pat = ([1, 2, 3, 1, 2, 4, 1, 2, 3] + hist)[-rng.randint(1, 10):]
+            ra = a.speculate(0, pat, 8, 2.0, 0.0, 0.05, use_tree_spec=True)
+            rb = b.speculate(0, pat, 8, 2.0, 0.0, 0.05, use_tree_spec=True)
+            gu.assert_cand(ra, gu.cand_dict(rb))
