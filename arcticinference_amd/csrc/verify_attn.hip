@@ -144,7 +144,10 @@ __global__ void __launch_bounds__(256, 2) verify_attn_kernel(AttnParams P) {
       if (more) load_tile(tt + kTile, k_next, v_stage);
 
       // ---- S^T tiles and online softmax, per 16-row query tile ---------------------------------
-      bf16x8 pfrag[MTQ];
+      // P is split into a bf16 head and a bf16 tail (p = hi + lo up to 2^-17 relative): the kernel is
+      // HBM-bound with the matrix pipe ~5 % busy, so a second P.V MFMA is free and removes the 2^-9
+      // relative rounding a single bf16 P would put on every term
+      bf16x8 pfrag[MTQ], pfrag_lo[MTQ];
 #pragma unroll
       for (int mt = 0; mt < MTQ; ++mt) {
         f32x4 st[2];
@@ -192,10 +195,14 @@ __global__ void __launch_bounds__(256, 2) verify_attn_kernel(AttnParams P) {
         m_run[mt] = m_new;
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) o_acc[mt][dt] *= alpha;
-        bf16x8 pf;
+        bf16x8 pf, pl;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pf[e] = static_cast<__bf16>(pv[e]);
+        for (int e = 0; e < 8; ++e) {
+          pf[e] = static_cast<__bf16>(pv[e]);
+          pl[e] = static_cast<__bf16>(pv[e] - static_cast<float>(pf[e]));
+        }
         pfrag[mt] = pf;
+        pfrag_lo[mt] = pl;
       }
 
       // ---- O^T += V^T P^T : A = V^T fragment via transposing LDS reads -----------------------------
@@ -214,8 +221,10 @@ __global__ void __launch_bounds__(256, 2) verify_attn_kernel(AttnParams P) {
           const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
           const bf16x8 vfrag = __builtin_bit_cast(bf16x8, both);
 #pragma unroll
-          for (int mt = 0; mt < MTQ; ++mt)
+          for (int mt = 0; mt < MTQ; ++mt) {
             o_acc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pfrag[mt], o_acc[mt][dt], 0, 0, 0);
+            o_acc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pfrag_lo[mt], o_acc[mt][dt], 0, 0, 0);
+          }
         }
       }
 

@@ -212,8 +212,9 @@ def test_verify_attention(cfg):
                                   torch.tensor(cfg["ctxs"], dtype=torch.int32, device=DEV),
                                   torch.tensor(qsl, device=DEV), max(cfg["q_lens"]), max(cfg["ctxs"]), scale)
     err = (got.float().cpu() - want).abs()
-    # tolerance stated by BASELINE.json north_star: 1e-3 in bf16 (outputs are O(0.1-1), bf16 ulp 2^-8 relative)
-    assert torch.allclose(got.float().cpu(), want, atol=1e-3, rtol=1.6e-2), f"max abs err {err.max()}"
+    # tolerance: BASELINE.json north_star asks for 1e-3 in bf16 -> atol 1e-3 plus one bf16 rounding of the
+    # output itself (relative 2^-8); internally P.V runs at ~fp32 accuracy (bf16 hi+lo split)
+    assert torch.allclose(got.float().cpu(), want, atol=1e-3, rtol=2 ** -8), f"max abs err {err.max()}"
 
 
 def test_verify_attention_strided_q_and_peaked_softmax():
@@ -230,15 +231,16 @@ def test_verify_attention_strided_q_and_peaked_softmax():
     qv = bd[:, :Hq * D].view(-1, Hq, D)
     got = _ops().verify_attention(qv, kc.to(DEV), vc.to(DEV), bt.to(DEV), torch.tensor([200, 333], dtype=torch.int32, device=DEV),
                                   torch.tensor(qsl, device=DEV), 4, 333, 1.0 / D ** 0.5)
-    assert torch.allclose(got.float().cpu(), want, atol=1e-3, rtol=1.6e-2)
+    assert torch.allclose(got.float().cpu(), want, atol=1e-3, rtol=2 ** -8)
 
 
 # ------------------------------------------------------------------------------------------------
 # A7-A10 LSTM speculator
 # ------------------------------------------------------------------------------------------------
-def _check_tokens(got, want_toks, want_logits, tag):
-    """Tokens must agree except where the oracle's own top-2 logits are within one bf16 step
-    (accumulation order differs between MFMA tiles and the CPU GEMM)."""
+def _check_tokens(got, want_toks, want_logits, tag, ulps=1):
+    """Tokens must agree except where the oracle's own top-2 logits are within `ulps` bf16 steps
+    (accumulation order differs between MFMA tiles and the CPU GEMM; on the fp8 head a one-ulp
+    difference in a bf16 activation can flip its e4m3 code, a 6 % step on that element)."""
     B, k = want_toks.shape
     bad = 0
     for b in range(B):
@@ -248,7 +250,7 @@ def _check_tokens(got, want_toks, want_logits, tag):
             lg = want_logits[h][b].float()
             top = float(lg.max())
             mine = float(lg[int(got[b, h])])
-            assert top - mine <= max(abs(top), 1e-3) * 2 ** -7, f"{tag}: row {b} head {h}: {mine} vs max {top}"
+            assert top - mine <= max(abs(top), 1e-3) * 2 ** -7 * ulps, f"{tag}: row {b} head {h}: {mine} vs max {top}"
             bad += 1
             break  # later heads of this row follow a different token
     assert bad <= max(1, B * k // 10), f"{tag}: {bad} near-tie mismatches"
@@ -270,7 +272,7 @@ def test_lstm_speculator_small(B, fp8):
                                              return_logits=True)
     got = m.generate_proposals(ids.to(DEV), hidden.to(DEV), 3).cpu()
     assert got.shape == (B, 3) and got.dtype == torch.int64
-    _check_tokens(got, want, logits, f"B={B} fp8={use_fp8}")
+    _check_tokens(got, want, logits, f"B={B} fp8={use_fp8}", ulps=4 if use_fp8 else 1)
 
 
 def test_lstm_hidden_index_and_errors():
