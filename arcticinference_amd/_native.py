@@ -53,6 +53,8 @@ _SIGNATURES = {
     "aic_last_error": (c_char_p, []),
     "aic_version": (c_int, []),
     "aic_device_count": (c_int, []),
+    "aic_profile_enable": (c_int, [c_int]),
+    "aic_profile_read": (c_int, [POINTER(c_double), POINTER(c_int)]),
     "aic_st_create": (c_void_p, [c_int]),
     "aic_st_destroy": (None, [c_void_p]),
     "aic_st_num_seqs": (c_int, [c_void_p]),

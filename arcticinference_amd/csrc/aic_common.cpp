@@ -3,6 +3,8 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <utility>
+#include <vector>
 
 namespace aic {
 
@@ -25,9 +27,53 @@ bool has_device() {
   return cached == 1;
 }
 
+static bool g_prof = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pairs;
+static size_t g_used = 0;
+static bool g_open = false;
+
+bool profile_enabled() { return g_prof; }
+void profile_begin(hipStream_t stream) {
+  if (!g_prof) return;
+  if (g_used == g_pairs.size()) {
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    g_pairs.emplace_back(a, b);
+  }
+  g_open = hipEventRecord(g_pairs[g_used].first, stream) == hipSuccess;
+}
+void profile_end(hipStream_t stream) {
+  if (!g_prof || !g_open) return;
+  if (hipEventRecord(g_pairs[g_used].second, stream) == hipSuccess) ++g_used;
+  g_open = false;
+}
+
 }  // namespace aic
 
 extern "C" {
+// profiling of the dominant kernel (verify_attn_kernel): enable / reset, then read {sum of device
+// time in microseconds, number of launches}.  Reading synchronises the recorded events.
+int aic_profile_enable(int on) {
+  aic::g_prof = on != 0;
+  aic::g_used = 0;
+  return AIC_OK;
+}
+int aic_profile_read(double* total_us, int* launches) {
+  double us = 0.0;
+  int n = 0;
+  for (size_t i = 0; i < aic::g_used; ++i) {
+    float ms = 0.0f;
+    if (hipEventSynchronize(aic::g_pairs[i].second) != hipSuccess) continue;
+    if (hipEventElapsedTime(&ms, aic::g_pairs[i].first, aic::g_pairs[i].second) == hipSuccess) {
+      us += static_cast<double>(ms) * 1000.0;
+      ++n;
+    }
+  }
+  if (total_us) *total_us = us;
+  if (launches) *launches = n;
+  aic::g_used = 0;
+  return AIC_OK;
+}
 const char* aic_last_error(void) { return aic::g_err; }
 int aic_version(void) { return 100; }
 int aic_device_count(void) {

@@ -14,6 +14,12 @@ namespace aic {
 void set_error(const char* fmt, ...);
 bool has_device();
 
+// Optional device timing of one named kernel: when enabled, launch sites bracket that kernel with a
+// HIP event pair on the launch stream; aic_profile_read() synchronises the events and sums them.
+bool profile_enabled();
+void profile_begin(hipStream_t stream);
+void profile_end(hipStream_t stream);
+
 #define AIC_HIP_TRY(expr)                                                                  \
   do {                                                                                     \
     hipError_t _e = (expr);                                                                \

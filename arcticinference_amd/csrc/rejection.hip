@@ -310,7 +310,7 @@ static int run_rejection(const void* logits, int64_t row_stride, int vocab, cons
                          const int32_t* cu, const int32_t* bonus, const float* temperature, const double* uniform,
                          const float* noise, int batch, int rows, int max_spec_len, int32_t* out, int32_t* nacc,
                          int32_t* last, int32_t* hidx, void* workspace, hipStream_t stream, bool random) {
-  const int S = pick_splits(rows, vocab);
+  const int S = rows > 0 ? pick_splits(rows, vocab) : 1;  // a step without drafts still emits bonus tokens
   int seg_len = (vocab + S - 1) / S;
   seg_len = (seg_len + kSegQuantum - 1) / kSegQuantum * kSegQuantum;
   const int n_splits = (vocab + seg_len - 1) / seg_len;

@@ -58,11 +58,21 @@ struct AttnParams {
   float sm_scale;
 };
 
+// Byte offset of 16-byte chunk `ch` (0..15) of token `t` (0..31) in the wave's V tile.  256-byte rows with
+// the chunk index XOR-ed by a function of the row (cdna guide T10, image (b)), and token groups 4-7 /
+// 8-11 swapped between rows so that the two 4-row blocks a 32-lane half reads transposed sit 8 rows
+// apart: both the ds_write_b128 fill and the ds_read_b64_tr_b16 reads are then bank-conflict free.
+__device__ __forceinline__ int v_tile_off(int t, int ch) {
+  const int row = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
 template <int MTQ>
-__global__ void __launch_bounds__(256, 2) verify_attn_kernel(AttnParams P) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) verify_attn_kernel(AttnParams P) {
   __shared__ uint4 v_lds[4][kTile * 16];  // per wave: 32 tokens x 256 B
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps loop control scalar
   const int g = lane >> 4, c16 = lane & 15;
   const int Hkv = P.num_kv_heads, Hq = P.num_q_heads, G = Hq / Hkv;
   const int req = blockIdx.x / Hkv, h = blockIdx.x - req * Hkv;
@@ -82,6 +92,7 @@ __global__ void __launch_bounds__(256, 2) verify_attn_kernel(AttnParams P) {
 
   const int64_t kv_row = static_cast<int64_t>(Hkv) * kD;  // elements between consecutive tokens of a page
   const int32_t* btab = P.block_table + static_cast<int64_t>(req) * P.max_blocks;
+  const int bs = P.block_size;  // multiple of 16: a 16-token group never straddles two pages
 
   // ---- query fragments (B operand of S^T = K Q^T): lane (row c16, k-group g) ----------------------
   uint4 qf[MTQ][4];
@@ -109,39 +120,61 @@ __global__ void __launch_bounds__(256, 2) verify_attn_kernel(AttnParams P) {
     for (int dt = 0; dt < 8; ++dt) o_acc[mt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  uint4* vt = v_lds[wave];
+  char* vt = reinterpret_cast<char*>(v_lds[wave]);
+
+  // Page lookup for the two 16-token groups of a tile.  It is wave-uniform (scalar), and it is issued
+  // one tile AHEAD of the data loads that use it: a block-table load placed between the data loads
+  // would serialise them (vmcnt retires in order), which costs one HBM round trip per group.
+  struct TilePages {
+    int64_t base0, base1;  // element offset of each group's first token row inside the cache
+    int first0, first1;    // first token of each group (clamped into the context)
+  };
+  const int last_group = (ctx - 1) & ~15;
+  auto tile_pages = [&](int tt) -> TilePages {
+    TilePages tp;
+    tp.first0 = min(tt, last_group);
+    tp.first1 = min(tt + 16, last_group);
+    const int b0 = btab[tp.first0 / bs], b1 = btab[tp.first1 / bs];
+    tp.base0 = static_cast<int64_t>(b0) * P.block_stride + static_cast<int64_t>(tp.first0 % bs) * kv_row + h * kD;
+    tp.base1 = static_cast<int64_t>(b1) * P.block_stride + static_cast<int64_t>(tp.first1 % bs) * kv_row + h * kD;
+    return tp;
+  };
 
   // loads of one 32-token tile: K as MFMA A fragments (token c16, d = 32 s + 8 g ..), V row-contiguous
-  auto load_tile = [&](int tt, uint4(&kf)[2][4], uint4(&vf)[8]) {
+  auto load_tile = [&](int tt, const TilePages& tp, uint4(&kf)[2][4], uint4(&vf)[8]) {
 #pragma unroll
     for (int th = 0; th < 2; ++th) {
-      const int tok = min(tt + 16 * th + c16, ctx - 1);  // never touch pages past the context
-      const int blk = btab[tok / P.block_size];
-      const uint16_t* kp = P.k_cache + static_cast<int64_t>(blk) * P.block_stride +
-                           static_cast<int64_t>(tok % P.block_size) * kv_row + h * kD + 8 * g;
+      const int first = th ? tp.first1 : tp.first0;
+      const int off = min(tt + 16 * th + c16, ctx - 1) - first;  // 0..15, never past the context
+      const uint16_t* kp = P.k_cache + (th ? tp.base1 : tp.base0) + static_cast<int64_t>(off) * kv_row + 8 * g;
 #pragma unroll
       for (int s = 0; s < 4; ++s) kf[th][s] = *reinterpret_cast<const uint4*>(kp + 32 * s);
     }
 #pragma unroll
     for (int iv = 0; iv < 8; ++iv) {
-      const int tok = min(tt + 4 * iv + g, ctx - 1);
-      const int blk = btab[tok / P.block_size];
-      const uint16_t* vp = P.v_cache + static_cast<int64_t>(blk) * P.block_stride +
-                           static_cast<int64_t>(tok % P.block_size) * kv_row + h * kD + 8 * c16;
+      const int th = iv >> 2;
+      const int first = th ? tp.first1 : tp.first0;
+      const int off = min(tt + 4 * iv + g, ctx - 1) - first;
+      const uint16_t* vp = P.v_cache + (th ? tp.base1 : tp.base0) + static_cast<int64_t>(off) * kv_row + 8 * c16;
       vf[iv] = *reinterpret_cast<const uint4*>(vp);
     }
   };
 
   if (t_begin < t_end) {
     uint4 k_cur[2][4], v_stage[8];
-    load_tile(t_begin, k_cur, v_stage);
+    TilePages pages = tile_pages(t_begin);
+    load_tile(t_begin, pages, k_cur, v_stage);
+    pages = tile_pages(t_begin + kTile);
 #pragma unroll
-    for (int iv = 0; iv < 8; ++iv) vt[(4 * iv + g) * 16 + c16] = v_stage[iv];
+    for (int iv = 0; iv < 8; ++iv) *reinterpret_cast<uint4*>(vt + v_tile_off(4 * iv + g, c16)) = v_stage[iv];
 
     for (int tt = t_begin; tt < t_end; tt += kTile) {
       const bool more = tt + kTile < t_end;
       uint4 k_next[2][4];
-      if (more) load_tile(tt + kTile, k_next, v_stage);
+      if (more) {
+        load_tile(tt + kTile, pages, k_next, v_stage);
+        pages = tile_pages(tt + 2 * kTile);  // consumed one iteration later
+      }
 
       // ---- S^T tiles and online softmax, per 16-row query tile ---------------------------------
       // P is split into a bf16 head and a bf16 tail (p = hi + lo up to 2^-17 relative): the kernel is
@@ -208,15 +241,15 @@ __global__ void __launch_bounds__(256, 2) verify_attn_kernel(AttnParams P) {
       // ---- O^T += V^T P^T : A = V^T fragment via transposing LDS reads -----------------------------
       {
         const int q4 = c16 >> 2, p4 = c16 & 3;
-        const uint16_t* vbase = reinterpret_cast<const uint16_t*>(vt);
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) {
-          const uint16_t* a_lo = vbase + (4 * g + q4) * 128 + dt * 16 + 4 * p4;
-          const uint16_t* a_hi = a_lo + 16 * 128;
+          // lane 4q+p of a 16-lane group supplies row q of the block, columns 4p..4p+3 (8 bytes)
+          const char* a_lo = vt + v_tile_off(4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
+          const char* a_hi = vt + v_tile_off(16 + 4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (s16x4 __attribute__((address_space(3)))*)(const_cast<uint16_t*>(a_lo)));
+              (s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(a_lo)));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (s16x4 __attribute__((address_space(3)))*)(const_cast<uint16_t*>(a_hi)));
+              (s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(a_hi)));
           typedef __attribute__((ext_vector_type(8))) short s16x8;
           const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
           const bf16x8 vfrag = __builtin_bit_cast(bf16x8, both);
@@ -230,7 +263,7 @@ __global__ void __launch_bounds__(256, 2) verify_attn_kernel(AttnParams P) {
 
       if (more) {
 #pragma unroll
-        for (int iv = 0; iv < 8; ++iv) vt[(4 * iv + g) * 16 + c16] = v_stage[iv];
+        for (int iv = 0; iv < 8; ++iv) *reinterpret_cast<uint4*>(vt + v_tile_off(4 * iv + g, c16)) = v_stage[iv];
 #pragma unroll
         for (int th = 0; th < 2; ++th)
 #pragma unroll
@@ -334,13 +367,20 @@ int aic_verify_attention(const void* q, int64_t q_stride, const void* k_cache, c
     return AIC_ERR_UNSUPPORTED;
   }
   AIC_REQUIRE(q_stride % 8 == 0 && out_stride % 2 == 0 && block_stride % 8 == 0, "strides must keep 16-byte alignment");
+  if (block_size % 16 != 0) {
+    set_error("block_size %d not supported (must be a multiple of 16)", block_size);
+    return AIC_ERR_UNSUPPORTED;
+  }
   AIC_NEED_DEVICE();
 
   const int G = num_q_heads / num_kv_heads;
   const int max_rows = max_q_len * G;
-  const int mtq = max_rows <= 16 ? 1 : 2;
+  // rows per request in the common case decide the tile shape; the few long (suffix) drafts of a mixed
+  // batch take extra row groups instead of making every request pay for a two-tile kernel
+  const int avg_rows = (num_tokens + batch - 1) / batch * G;
+  const int mtq = (max_rows <= 16 || avg_rows <= 24) ? 1 : 2;
   const int m_groups = (max_rows + mtq * 16 - 1) / (mtq * 16);
-  int n_splits = pick_splits(batch, num_kv_heads, m_groups, max_seq_len);
+  int n_splits = pick_splits(batch, num_kv_heads, 1, max_seq_len);
   const size_t rows = static_cast<size_t>(num_tokens) * num_q_heads;
   while (n_splits > 1 && static_cast<size_t>(n_splits) * 4 * rows * (kD + 2) * sizeof(float) > workspace_bytes) --n_splits;
   AIC_REQUIRE(static_cast<size_t>(n_splits) * 4 * rows * (kD + 2) * sizeof(float) <= workspace_bytes,
@@ -367,10 +407,12 @@ int aic_verify_attention(const void* q, int64_t q_stride, const void* k_cache, c
 
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(batch * num_kv_heads, n_splits, m_groups);
+  profile_begin(s);
   if (mtq == 1)
     hipLaunchKernelGGL(verify_attn_kernel<1>, grid, dim3(256), 0, s, P);
   else
     hipLaunchKernelGGL(verify_attn_kernel<2>, grid, dim3(256), 0, s, P);
+  profile_end(s);
   int rc = launch_status("verify_attn_kernel");
   if (rc != AIC_OK) return rc;
   hipLaunchKernelGGL(verify_attn_combine_kernel, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s, P.ws_o,

@@ -1,0 +1,305 @@
+"""Stand-alone driver of the spec-decode hot loop — the part of GPUModelRunnerPatch.execute_model
+(/root/reference/arctic_inference/vllm/model_runner.py:218-524, call stack in SURVEY.md §3.3) that this
+repository owns: verify attention for the step's (1 + n_draft) query tokens per request, rejection
+acceptance, suffix-cache update + batched suffix proposal, LSTM proposal, and the selection rule
+(`suffix wins iff score >= num_speculative_tokens`, :555-566, `suffix_ids[i] or lstm_ids[i]`, :597-601).
+
+The target model's dense layers (QKV / MLP GEMMs, norms, LM head) belong to vLLM and are not part of
+the path: their outputs (per-layer q, sample hidden states, verify logits) are synthetic tensors of the
+real shapes.  bench.py and the integration tests drive this class; the vLLM patch layer
+(arcticinference_amd/vllm_plugin/) calls the same ops from inside vLLM's model runner.
+
+Ordering is MI355X-first: everything the GPU needs for drafting (last accepted token, hidden-state
+row) is produced ON the device by the acceptance kernel, so the LSTM draft is enqueued before the
+host touches the step's results and runs while the host updates the suffix trees.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import ops
+from .speculator import ArcticLSTMSpeculator
+from .suffix_cache import SuffixCache, SuffixSpecResult
+
+MAX_SPEC_LEN = 32  # vllm.v1.sample.rejection_sampler.MAX_SPEC_LEN (model_runner.py:42, :716)
+
+
+@dataclass
+class SpecConfig:
+    """Names and defaults of ArcticSpeculativeConfig (/root/reference/arctic_inference/vllm/config.py:55-62,:93-102)."""
+    method: str = "arctic"
+    num_speculative_tokens: int = 3
+    enable_suffix_decoding: bool = True
+    suffix_cache_max_depth: int = 64
+    suffix_max_spec_factor: float = 1.0
+    suffix_max_spec_offset: float = 0.0
+    suffix_min_token_prob: float = 0.1
+    disable_by_batch_size: int = 64
+
+
+@dataclass
+class ModelShape:
+    num_layers: int = 32
+    num_q_heads: int = 32
+    num_kv_heads: int = 8
+    head_size: int = 128
+    hidden_size: int = 4096
+    vocab_size: int = 128256
+    block_size: int = 16
+
+
+@dataclass
+class StepStats:
+    emitted: int = 0
+    accepted: int = 0
+    drafted: int = 0
+    num_drafts: int = 0
+    suffix_used: int = 0
+
+
+class RequestState:
+    __slots__ = ("req_id", "tokens", "num_prompt", "drafts", "blocks")
+
+    def __init__(self, req_id, prompt: Sequence[int], blocks: np.ndarray):
+        self.req_id = req_id
+        self.tokens: List[int] = list(prompt)   # prompt + every sampled token (token_ids_cpu row)
+        self.num_prompt = len(prompt)
+        self.drafts: List[int] = []
+        self.blocks = blocks
+
+
+class HotPathEngine:
+    """One rank of the hot loop.  With sp_size > 1 the attention runs Ulysses-style on this rank's head
+    slice (see arcticinference_amd/ulysses.py); everything else is replicated, as in the reference."""
+
+    def __init__(self, shape: ModelShape, spec: SpecConfig, max_num_seqs: int, max_model_len: int,
+                 speculator: Optional[ArcticLSTMSpeculator], device: str = "cuda", ulysses=None, seed: int = 0):
+        self.shape, self.spec = shape, spec
+        self.device = torch.device(device)
+        self.max_num_seqs, self.max_model_len = max_num_seqs, max_model_len
+        self.drafter = speculator
+        self.ulysses = ulysses
+        self.sp = 1 if ulysses is None else ulysses.sp_size
+        self.suffix_cache = SuffixCache(spec.suffix_cache_max_depth) if (
+            spec.enable_suffix_decoding or spec.method == "suffix") else None
+        s = shape
+        self.hq_local = s.num_q_heads // self.sp
+        self.hkv_local = max(1, s.num_kv_heads // self.sp)
+        self.blocks_per_seq = (max_model_len + s.block_size - 1) // s.block_size
+        nb = max_num_seqs * self.blocks_per_seq
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        # per-layer paged KV caches [2, num_blocks, block_size, Hkv_local, D] (llama_swiftkv.py:617 layout)
+        self.kv = [torch.empty(2, nb, s.block_size, self.hkv_local, s.head_size, dtype=torch.bfloat16,
+                               device=self.device).normal_(generator=g) for _ in range(s.num_layers)]
+        self.max_tokens = max_num_seqs * (MAX_SPEC_LEN + 1)
+        tq = self.max_tokens
+        # synthetic outputs of the target model's dense layers (real shapes)
+        self.q_buf = torch.empty(tq, s.num_q_heads * s.head_size, dtype=torch.bfloat16, device=self.device).normal_(generator=g)
+        self.k_buf = torch.empty(tq, s.num_kv_heads * s.head_size, dtype=torch.bfloat16, device=self.device).normal_(generator=g)
+        self.v_buf = torch.empty(tq, s.num_kv_heads * s.head_size, dtype=torch.bfloat16, device=self.device).normal_(generator=g)
+        self.hidden = torch.empty(tq, s.hidden_size, dtype=torch.bfloat16, device=self.device).normal_(generator=g)
+        self.logits = torch.empty(tq, s.vocab_size, dtype=torch.bfloat16, device=self.device).normal_(generator=g)
+        self.attn_out = torch.empty(tq, self.hq_local * s.head_size, dtype=torch.bfloat16, device=self.device)
+        perm = torch.randperm(nb, generator=torch.Generator().manual_seed(seed)).numpy().astype(np.int32)
+        self._free_blocks = [perm[i * self.blocks_per_seq:(i + 1) * self.blocks_per_seq] for i in range(max_num_seqs)]
+        self.requests: List[Optional[RequestState]] = [None] * max_num_seqs
+        self.block_table = torch.zeros(max_num_seqs, self.blocks_per_seq, dtype=torch.int32, device=self.device)
+        self.sm_scale = s.head_size ** -0.5
+        self.stats = StepStats()
+        self.last_suffix_stats: Dict = {}
+
+    # -- request management ---------------------------------------------------------------------------
+    def add_request(self, slot: int, req_id, prompt: Sequence[int], first_token: int) -> None:
+        """Admit a request whose prompt has been prefilled (its KV is taken as resident) and whose first
+        token has been sampled.  Mirrors the first pass through _update_suffix_cache (:657-673)."""
+        old = self.requests[slot]
+        blocks = self._free_blocks[slot]
+        r = RequestState(req_id, prompt, blocks)
+        self.requests[slot] = r
+        self.block_table[slot].copy_(torch.from_numpy(blocks), non_blocking=False)
+        if self.suffix_cache is not None:
+            if old is not None and self.suffix_cache.has_cached_prompt(old.req_id):
+                self.suffix_cache.evict_prompt(old.req_id)   # model_runner.py:675-678
+            self.suffix_cache.cache_prompt(req_id, r.tokens[:r.num_prompt])
+            self.suffix_cache.update_response(req_id, [int(first_token)])
+        r.tokens.append(int(first_token))
+
+    def add_requests(self, slots, req_ids, prompts, first_tokens, n_threads: int = 8) -> None:
+        if self.suffix_cache is not None:
+            for s in slots:
+                old = self.requests[s]
+                if old is not None and self.suffix_cache.has_cached_prompt(old.req_id):
+                    self.suffix_cache.evict_prompt(old.req_id)
+            self.suffix_cache.cache_prompts(list(req_ids), [list(p) for p in prompts], n_threads=n_threads)
+        for s, rid, p, ft in zip(slots, req_ids, prompts, first_tokens):
+            r = RequestState(rid, p, self._free_blocks[s])
+            self.requests[s] = r
+            self.block_table[s].copy_(torch.from_numpy(r.blocks))
+            if self.suffix_cache is not None:
+                self.suffix_cache.update_response(rid, [int(ft)])
+            r.tokens.append(int(ft))
+
+    # -- one engine step --------------------------------------------------------------------------------
+    def step(self, next_truth) -> List[List[int]]:
+        """`next_truth(req, n)` -> the target model's greedy tokens for the next n positions of `req`
+        (the synthetic target: its verify logits get these tokens planted as arg-max).
+        Returns the tokens emitted per live request."""
+        s, spec, dev = self.shape, self.spec, self.device
+        live = [i for i, r in enumerate(self.requests) if r is not None]
+        B = len(live)
+        if B == 0:
+            return []
+        reqs = [self.requests[i] for i in live]
+        n_draft = np.array([len(r.drafts) for r in reqs], dtype=np.int32)
+        q_len = n_draft + 1
+        T = int(q_len.sum())
+        qsl = np.zeros(B + 1, dtype=np.int32)
+        np.cumsum(q_len, out=qsl[1:])
+        # context after this step's tokens are written: everything sampled so far + the drafts
+        ctx = np.array([len(r.tokens) + len(r.drafts) for r in reqs], dtype=np.int32)
+        max_q, max_ctx = int(q_len.max()), int(ctx.max())
+
+        # planted verify logits: row (request i, position p) gets the target's token for that position
+        truth = [next_truth(r, int(q_len[i])) for i, r in enumerate(reqs)]
+        plant_tok = np.concatenate([np.asarray(t, dtype=np.int64) for t in truth])
+        draft_flat = np.concatenate([np.asarray(r.drafts, dtype=np.int32) for r in reqs]) if n_draft.sum() else np.zeros(0, np.int32)
+        # target rows = all but the last row of each request; bonus row = the last one (model_runner.py:394-404)
+        is_bonus = np.zeros(T, dtype=bool)
+        is_bonus[qsl[1:] - 1] = True
+        target_rows = np.nonzero(~is_bonus)[0]
+        bonus_rows = qsl[1:] - 1
+
+        h2d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt, non_blocking=True)
+        d_seq = h2d(ctx, torch.int32)
+        d_qsl = h2d(qsl, torch.int32)
+        d_rows = h2d(np.arange(T), torch.int64)
+        d_plant = h2d(plant_tok, torch.int64)
+        d_draft = h2d(draft_flat, torch.int32)
+        d_cu = h2d(np.cumsum(n_draft), torch.int32)
+        d_trows = h2d(target_rows, torch.int64)
+        d_brows = h2d(bonus_rows, torch.int64)
+        slots = torch.tensor(live, dtype=torch.int64, device=dev)
+        bt = self.block_table.index_select(0, slots) if B != self.max_num_seqs else self.block_table
+
+        # (a) KV of the step's tokens for every layer in one launch (A16), then (b) verify attention per layer
+        self._write_kv(reqs, q_len, qsl, T)
+        self._attention_layers(T, bt, d_seq, d_qsl, max_q, max_ctx)
+
+        # (c) verify logits: plant, accept, un-plant
+        lg = self.logits[:T]
+        saved = lg[d_rows, d_plant].clone()
+        lg[d_rows, d_plant] = 30.0
+        bonus = torch.argmax(lg.index_select(0, d_brows), dim=-1).to(torch.int32)  # vLLM's sampler on the bonus rows
+        tl = lg.index_select(0, d_trows) if len(target_rows) != T else lg
+        max_spec = int(max(n_draft.max(), 1))
+        rej = ops.rejection_sample(tl, d_draft, d_cu, bonus, max_spec)
+        lg[d_rows, d_plant] = saved
+
+        # (d) LSTM draft straight from the device-side acceptance results (no host round trip)
+        lstm_out = None
+        use_lstm = spec.method in ("arctic", "mlp_speculator") and self.drafter is not None and B <= spec.disable_by_batch_size
+        if use_lstm:
+            lstm_out = self.drafter.generate_proposals(rej.last_token, self.hidden, spec.num_speculative_tokens,
+                                                       hidden_index=rej.hidden_index)
+        out_host = rej.output_token_ids.cpu().numpy()   # first (and only blocking) D2H of the step
+
+        # (e) host: parse, commit, update the suffix trees while the LSTM kernels run
+        emitted: List[List[int]] = []
+        for i, r in enumerate(reqs):
+            row = out_host[i]
+            toks = [int(t) for t in row if t != -1 and t < s.vocab_size]   # parse_output (:456-459)
+            emitted.append(toks)
+            self.stats.emitted += len(toks)
+            if n_draft[i]:
+                self.stats.num_drafts += 1
+                self.stats.drafted += int(n_draft[i])
+                self.stats.accepted += len(toks) - 1
+            r.tokens.extend(toks)
+            r.drafts = []
+        if B > spec.disable_by_batch_size:
+            return emitted
+        suffix_res: Optional[List[SuffixSpecResult]] = None
+        if self.suffix_cache is not None:
+            for r, toks in zip(reqs, emitted):
+                if toks:
+                    self.suffix_cache.update_response(r.req_id, toks)          # _update_suffix_cache (:657-678)
+            suffix_res = self._propose_suffix(reqs, emitted)
+        # (f) merge (:555-566, :595-601)
+        lstm_host = lstm_out.cpu().numpy() if lstm_out is not None else None
+        min_score = 0 if spec.method == "suffix" else spec.num_speculative_tokens
+        for i, r in enumerate(reqs):
+            room = self.max_model_len - len(r.tokens) - 1
+            drafts: List[int] = []
+            if suffix_res is not None and suffix_res[i].score >= min_score and suffix_res[i].token_ids:
+                drafts = list(suffix_res[i].token_ids)
+                self.stats.suffix_used += 1
+            elif lstm_host is not None and emitted[i]:
+                k = min(spec.num_speculative_tokens, room)
+                drafts = [int(t) for t in lstm_host[i, :max(k, 0)]]
+            r.drafts = drafts[:max(room, 0)]
+        return emitted
+
+    # -- pieces -------------------------------------------------------------------------------------------
+    def _propose_suffix(self, reqs, emitted) -> List[SuffixSpecResult]:
+        """propose_suffix_draft_token_ids (model_runner.py:680-744) for the whole batch at once."""
+        cfg = self.spec
+        ids, pats, mst, fac, off, mpr = [], [], [], [], [], []
+        where = []
+        out = [SuffixSpecResult() for _ in reqs]
+        for i, (r, toks) in enumerate(zip(reqs, emitted)):
+            if not toks:
+                continue
+            end_idx = len(r.tokens)
+            if end_idx >= self.max_model_len:
+                continue
+            size = min(end_idx, cfg.suffix_cache_max_depth)
+            pattern = r.tokens[end_idx - size:end_idx]
+            m = min(MAX_SPEC_LEN, cfg.suffix_cache_max_depth, self.max_model_len - end_idx - 1)
+            ids.append(r.req_id)
+            pats.append(pattern)
+            mst.append(m)
+            fac.append(cfg.suffix_max_spec_factor)
+            off.append(cfg.suffix_max_spec_offset)
+            mpr.append(cfg.suffix_min_token_prob)
+            where.append(i)
+        if ids:
+            res = self.suffix_cache.speculate_batch(ids, pats, mst, fac, off, mpr, [True] * len(ids))
+            for i, x in zip(where, res):
+                out[i] = x
+            self.last_suffix_stats = self.suffix_cache.last_stats()
+        return out
+
+    def _write_kv(self, reqs, q_len, qsl, T) -> None:
+        s = self.shape
+        slot_map = np.empty(T, dtype=np.int64)
+        for i, r in enumerate(reqs):
+            first = len(r.tokens) - 1            # position of the last sampled token (not in the cache yet)
+            pos = first + np.arange(q_len[i])
+            slot_map[qsl[i]:qsl[i + 1]] = r.blocks[pos // s.block_size].astype(np.int64) * s.block_size + pos % s.block_size
+        d_slots = torch.from_numpy(slot_map).to(self.device, non_blocking=True)
+        # synthetic K/V of the new tokens: one [T, L * Hkv_local * D] activation like SwiftKV's fused projection
+        n = self.hkv_local * s.head_size
+        if not hasattr(self, "_kv_new"):
+            g = torch.Generator(device=self.device).manual_seed(1)
+            self._kv_new = torch.empty(2, self.max_tokens, s.num_layers * n, dtype=torch.bfloat16,
+                                       device=self.device).normal_(generator=g)
+            self._one = [torch.ones(1, device=self.device) for _ in range(s.num_layers)]
+            self._kc = [kv[0] for kv in self.kv]
+            self._vc = [kv[1] for kv in self.kv]
+        ops.reshape_and_cache_flash_bulk(self._kv_new[0, :T], self._kv_new[1, :T], self._kc, self._vc, d_slots, "auto",
+                                         self._one, self._one, self.hkv_local, s.head_size)
+
+    def _attention_layers(self, T, bt, d_seq, d_qsl, max_q, max_ctx) -> None:
+        s = self.shape
+        if self.ulysses is None:
+            q = self.q_buf[:T].view(T, s.num_q_heads, s.head_size)
+            out = self.attn_out[:T].view(T, s.num_q_heads, s.head_size)
+            for layer in range(s.num_layers):
+                kv = self.kv[layer]
+                ops.verify_attention(q, kv[0], kv[1], bt, d_seq, d_qsl, max_q, max_ctx, self.sm_scale, out=out)
+        else:
+            self.ulysses.attention_layers(self, T, bt, d_seq, d_qsl, max_q, max_ctx)

@@ -49,6 +49,11 @@ const char* aic_last_error(void);
 int aic_version(void);
 /* number of visible HIP devices (0 on a CPU-only box); never initialises a context */
 int aic_device_count(void);
+/* Device timing of the dominant kernel (verify_attn_kernel) for bench.py's roofline figure: while
+ * enabled every launch of that kernel is bracketed by a HIP event pair on its own stream;
+ * aic_profile_read synchronises them, returns {sum of microseconds, launches} and resets. */
+int aic_profile_enable(int on);
+int aic_profile_read(double* total_us, int* launches);
 
 /* ------------------------------------------------------------------------------------------
  * A1/A2  Suffix tree — replaces pybind module `_C` (csrc/suffix_cache/pybind.cc:24-38,

@@ -307,3 +307,14 @@ def test_quantize_fp8_per_tensor():
     q, s = _ops().quantize_fp8_per_tensor(x.to(DEV))
     assert torch.equal(s.cpu(), s_ref)
     assert torch.equal(q.cpu().view(torch.uint8), q_ref.view(torch.uint8))
+
+
+def test_rejection_no_drafts():
+    """A step in which no request has drafts (the first decode step): only bonus tokens come out."""
+    B, V = 4, 1000
+    cu = torch.zeros(B, dtype=torch.int32, device=DEV)
+    res = _ops().rejection_sample(torch.zeros(0, V, dtype=torch.bfloat16, device=DEV),
+                                  torch.zeros(0, dtype=torch.int32, device=DEV), cu,
+                                  torch.tensor([5, 6, 7, 8], dtype=torch.int32, device=DEV), 1)
+    assert res.output_token_ids.cpu().tolist() == [[5, -1], [6, -1], [7, -1], [8, -1]]
+    assert res.hidden_index.cpu().tolist() == [0, 1, 2, 3] and res.last_token.cpu().tolist() == [5, 6, 7, 8]
