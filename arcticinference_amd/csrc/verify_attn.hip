@@ -45,8 +45,8 @@ struct AttnParams {
   const int32_t* block_table;
   const int32_t* seq_lens;
   const int32_t* query_start_loc;
-  float* ws_o;   // [n_parts][T*Hq][D]
-  float* ws_ml;  // [n_parts][T*Hq][2]
+  float* ws_o;   // [n_splits][T*Hq][D]   one partial per workgroup
+  float* ws_ml;  // [n_splits][T*Hq][2]
   int64_t q_stride;
   int64_t block_stride;
   int max_blocks;
@@ -68,8 +68,12 @@ __device__ __forceinline__ int v_tile_off(int t, int ch) {
 }
 
 template <int MTQ>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) verify_attn_kernel(AttnParams P) {
-  __shared__ uint4 v_lds[4][kTile * 16];  // per wave: 32 tokens x 256 B
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ == 1 ? 3 : 2, MTQ == 1 ? 3 : 2))) verify_attn_kernel(AttnParams P) {
+  // per wave: one 32-token V tile (8 KiB); reused at the end for the cross-wave merge
+  constexpr int kMergeU4 = (8 * MTQ * 16 + 3 * MTQ * 16 * kD) / 4;
+  constexpr int kLdsU4 = 4 * kTile * 16 > kMergeU4 ? 4 * kTile * 16 : kMergeU4;
+  __shared__ uint4 v_lds_raw[kLdsU4];
+  uint4(*v_lds)[kTile * 16] = reinterpret_cast<uint4(*)[kTile * 16]>(v_lds_raw);
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps loop control scalar
@@ -140,58 +144,83 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     return tp;
   };
 
-  // loads of one 32-token tile: K as MFMA A fragments (token c16, d = 32 s + 8 g ..), V row-contiguous
-  auto load_tile = [&](int tt, const TilePages& tp, uint4(&kf)[2][4], uint4(&vf)[8]) {
-#pragma unroll
-    for (int th = 0; th < 2; ++th) {
-      const int first = th ? tp.first1 : tp.first0;
-      const int off = min(tt + 16 * th + c16, ctx - 1) - first;  // 0..15, never past the context
-      const uint16_t* kp = P.k_cache + (th ? tp.base1 : tp.base0) + static_cast<int64_t>(off) * kv_row + 8 * g;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) kf[th][s] = *reinterpret_cast<const uint4*>(kp + 32 * s);
-    }
-#pragma unroll
-    for (int iv = 0; iv < 8; ++iv) {
-      const int th = iv >> 2;
-      const int first = th ? tp.first1 : tp.first0;
-      const int off = min(tt + 4 * iv + g, ctx - 1) - first;
-      const uint16_t* vp = P.v_cache + (th ? tp.base1 : tp.base0) + static_cast<int64_t>(off) * kv_row + 8 * c16;
-      vf[iv] = *reinterpret_cast<const uint4*>(vp);
-    }
-  };
+  // One 32-token tile: K as MFMA A fragments (token c16, d = 32 s + 8 g ..), V row-contiguous.
+  // The tile registers are named scalars on purpose: carried across the loop as arrays they are kept in
+  // scratch memory by the compiler whenever 3 waves per SIMD are requested.
+  uint4 k00, k01, k02, k03, k10, k11, k12, k13;  // k<th><s>
+  uint4 v0, v1, v2, v3, v4, v5, v6, v7;          // v<iv>
+#define AIC_LOAD_K(tt_, tp_)                                                                                   \
+  {                                                                                                            \
+    const int off0_ = min((tt_) + c16, ctx - 1) - (tp_).first0;                                                \
+    const int off1_ = min((tt_) + 16 + c16, ctx - 1) - (tp_).first1;                                           \
+    const uint16_t* kp0_ = P.k_cache + (tp_).base0 + static_cast<int64_t>(off0_) * kv_row + 8 * g;             \
+    const uint16_t* kp1_ = P.k_cache + (tp_).base1 + static_cast<int64_t>(off1_) * kv_row + 8 * g;             \
+    k00 = *reinterpret_cast<const uint4*>(kp0_);                                                               \
+    k01 = *reinterpret_cast<const uint4*>(kp0_ + 32);                                                          \
+    k02 = *reinterpret_cast<const uint4*>(kp0_ + 64);                                                          \
+    k03 = *reinterpret_cast<const uint4*>(kp0_ + 96);                                                          \
+    k10 = *reinterpret_cast<const uint4*>(kp1_);                                                               \
+    k11 = *reinterpret_cast<const uint4*>(kp1_ + 32);                                                          \
+    k12 = *reinterpret_cast<const uint4*>(kp1_ + 64);                                                          \
+    k13 = *reinterpret_cast<const uint4*>(kp1_ + 96);                                                          \
+  }
+#define AIC_V_ADDR(tt_, tp_, iv_)                                                                              \
+  (P.v_cache + ((iv_) >= 4 ? (tp_).base1 : (tp_).base0) +                                                      \
+   static_cast<int64_t>(min((tt_) + 4 * (iv_) + g, ctx - 1) - ((iv_) >= 4 ? (tp_).first1 : (tp_).first0)) * kv_row + 8 * c16)
+#define AIC_LOAD_V(tt_, tp_)                                                                                   \
+  {                                                                                                            \
+    v0 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 0));                                             \
+    v1 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 1));                                             \
+    v2 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 2));                                             \
+    v3 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 3));                                             \
+    v4 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 4));                                             \
+    v5 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 5));                                             \
+    v6 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 6));                                             \
+    v7 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 7));                                             \
+  }
+#define AIC_STORE_V(iv_, reg_) *reinterpret_cast<uint4*>(vt + v_tile_off(4 * (iv_) + g, c16)) = reg_;
 
+  // Software pipeline with ONE register set per operand: the registers of a tile are re-armed with the
+  // next tile's loads as soon as their last consumer has issued (V: right after its LDS write, K: right
+  // after the QK^T MFMAs), so each load has about a full iteration to land and the kernel stays under
+  // 168 VGPRs (3 waves per SIMD = 12 x 16 KiB in flight per CU).  Loads past a wave's range are clamped
+  // into the context by tile_pages(): always valid addresses, results never used.
   if (t_begin < t_end) {
-    uint4 k_cur[2][4], v_stage[8];
     TilePages pages = tile_pages(t_begin);
-    load_tile(t_begin, pages, k_cur, v_stage);
-    pages = tile_pages(t_begin + kTile);
-#pragma unroll
-    for (int iv = 0; iv < 8; ++iv) *reinterpret_cast<uint4*>(vt + v_tile_off(4 * iv + g, c16)) = v_stage[iv];
+    AIC_LOAD_V(t_begin, pages)
+    AIC_LOAD_K(t_begin, pages)
+    TilePages pages_next = tile_pages(t_begin + kTile);
 
     for (int tt = t_begin; tt < t_end; tt += kTile) {
-      const bool more = tt + kTile < t_end;
-      uint4 k_next[2][4];
-      if (more) {
-        load_tile(tt + kTile, pages, k_next, v_stage);
-        pages = tile_pages(tt + 2 * kTile);  // consumed one iteration later
-      }
+      const int tn = tt + kTile;
+      // 1. V(t) registers -> wave-private LDS tile; 2. re-arm them with V(t+1)
+      AIC_STORE_V(0, v0) AIC_STORE_V(1, v1) AIC_STORE_V(2, v2) AIC_STORE_V(3, v3)
+      AIC_STORE_V(4, v4) AIC_STORE_V(5, v5) AIC_STORE_V(6, v6) AIC_STORE_V(7, v7)
+      AIC_LOAD_V(tn, pages_next)
 
-      // ---- S^T tiles and online softmax, per 16-row query tile ---------------------------------
+      // 3. S^T tiles (K registers), online softmax per 16-row query tile
       // P is split into a bf16 head and a bf16 tail (p = hi + lo up to 2^-17 relative): the kernel is
-      // HBM-bound with the matrix pipe ~5 % busy, so a second P.V MFMA is free and removes the 2^-9
-      // relative rounding a single bf16 P would put on every term
+      // HBM-bound with the matrix pipe a few percent busy, so a second P.V MFMA is free and removes the
+      // 2^-9 relative rounding a single bf16 P would put on every term
+      f32x4 st[MTQ][2];
+#pragma unroll
+      for (int mt = 0; mt < MTQ; ++mt) {
+        f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#define AIC_QK(acc_, kreg_, s_) \
+  acc_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kreg_), __builtin_bit_cast(bf16x8, qf[mt][s_]), acc_, 0, 0, 0);
+        AIC_QK(a0, k00, 0) AIC_QK(a0, k01, 1) AIC_QK(a0, k02, 2) AIC_QK(a0, k03, 3)
+        AIC_QK(a1, k10, 0) AIC_QK(a1, k11, 1) AIC_QK(a1, k12, 2) AIC_QK(a1, k13, 3)
+#undef AIC_QK
+        st[mt][0] = a0;
+        st[mt][1] = a1;
+      }
+      // 4. re-arm the K registers with K(t+1); page lookup one tile ahead of its data loads
+      AIC_LOAD_K(tn, pages_next)
+      pages_next = tile_pages(tn + kTile);
+
       bf16x8 pfrag[MTQ], pfrag_lo[MTQ];
 #pragma unroll
       for (int mt = 0; mt < MTQ; ++mt) {
-        f32x4 st[2];
-#pragma unroll
-        for (int th = 0; th < 2; ++th) {
-          st[th] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-            st[th] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k_cur[th][s]),
-                                                             __builtin_bit_cast(bf16x8, qf[mt][s]), st[th], 0, 0, 0);
-        }
         // lane: query row c16, tokens tt + 16 th + 4 g + e
         const int limit = ctx - q_len + row_pos[mt];
         float sc[8];
@@ -202,7 +231,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
           for (int e = 0; e < 4; ++e) {
             const int tok = tt + 16 * th + 4 * g + e;
             const bool vis = row_ok[mt] && tok < t_end && tok <= limit;
-            const float v = vis ? st[th][e] * P.sm_scale : -INFINITY;
+            const float v = vis ? st[mt][th][e] * P.sm_scale : -INFINITY;
             sc[th * 4 + e] = v;
             tmax = fmaxf(tmax, v);
           }
@@ -238,7 +267,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         pfrag_lo[mt] = pl;
       }
 
-      // ---- O^T += V^T P^T : A = V^T fragment via transposing LDS reads -----------------------------
+      // 5. O^T += V^T P^T : A = V^T fragment via transposing LDS reads
       {
         const int q4 = c16 >> 2, p4 = c16 & 3;
 #pragma unroll
@@ -260,34 +289,78 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
           }
         }
       }
-
-      if (more) {
-#pragma unroll
-        for (int iv = 0; iv < 8; ++iv) *reinterpret_cast<uint4*>(vt + v_tile_off(4 * iv + g, c16)) = v_stage[iv];
-#pragma unroll
-        for (int th = 0; th < 2; ++th)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) k_cur[th][s] = k_next[th][s];
-      }
     }
   }
 
-  // ---- partial result of this wave: O^T accumulator -> ws_o[part][row][d], (m, l) -> ws_ml ----------
+#undef AIC_LOAD_K
+#undef AIC_LOAD_V
+#undef AIC_V_ADDR
+#undef AIC_STORE_V
+
+  // ---- merge the four waves of the workgroup (they hold disjoint token ranges of the same rows) ------
+  // through LDS, so one partial per workgroup and row goes to the workspace instead of four
+  __syncthreads();  // every wave is done with its V tile: the LDS is free
+  float* xm = reinterpret_cast<float*>(v_lds_raw);  // [4 waves][MTQ][16 rows] running max
+  float* xl = xm + 4 * MTQ * 16;                         // [4][MTQ][16] running sum
+  float* xo = xl + 4 * MTQ * 16;                         // [3 waves][MTQ][16 rows][128] rescaled O of waves 1..3
+#pragma unroll
+  for (int mt = 0; mt < MTQ; ++mt)
+    if (g == 0) {
+      xm[(wave * MTQ + mt) * 16 + c16] = m_run[mt];
+      xl[(wave * MTQ + mt) * 16 + c16] = l_run[mt];
+    }
+  __syncthreads();
+  float scale_w[MTQ], m_all[MTQ], l_all[MTQ];
+#pragma unroll
+  for (int mt = 0; mt < MTQ; ++mt) {
+    float M = -INFINITY;
+    for (int w = 0; w < 4; ++w) M = fmaxf(M, xm[(w * MTQ + mt) * 16 + c16]);
+    float L = 0.0f;
+    for (int w = 0; w < 4; ++w) {
+      const float mw = xm[(w * MTQ + mt) * 16 + c16];
+      if (mw > -INFINITY) L += xl[(w * MTQ + mt) * 16 + c16] * __expf(mw - M);
+    }
+    m_all[mt] = M;
+    l_all[mt] = L;
+    scale_w[mt] = m_run[mt] > -INFINITY ? __expf(m_run[mt] - M) : 0.0f;
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int mt = 0; mt < MTQ; ++mt)
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        float* dst = xo + ((static_cast<size_t>(wave - 1) * MTQ + mt) * 16 + c16) * kD + dt * 16 + 4 * g;
+        *reinterpret_cast<float4*>(dst) = make_float4(o_acc[mt][dt][0] * scale_w[mt], o_acc[mt][dt][1] * scale_w[mt],
+                                                       o_acc[mt][dt][2] * scale_w[mt], o_acc[mt][dt][3] * scale_w[mt]);
+      }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  const int bpart = blockIdx.y;  // one partial per workgroup
 #pragma unroll
   for (int mt = 0; mt < MTQ; ++mt) {
     if (!row_ok[mt]) continue;
     const int rr = row0 + mt * 16 + c16;
     const int pos = rr / G, gq = rr - pos * G;
     const int64_t grow = static_cast<int64_t>(q0 + pos) * Hq + h * G + gq;
-    float* op = P.ws_o + (static_cast<int64_t>(part) * P.total_rows + grow) * kD + 4 * g;
+    float* op = P.ws_o + (static_cast<int64_t>(bpart) * P.total_rows + grow) * kD + 4 * g;
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt)
-      *reinterpret_cast<float4*>(op + dt * 16) =
-          make_float4(o_acc[mt][dt][0], o_acc[mt][dt][1], o_acc[mt][dt][2], o_acc[mt][dt][3]);
+    for (int dt = 0; dt < 8; ++dt) {
+      float4 acc = make_float4(o_acc[mt][dt][0] * scale_w[mt], o_acc[mt][dt][1] * scale_w[mt],
+                               o_acc[mt][dt][2] * scale_w[mt], o_acc[mt][dt][3] * scale_w[mt]);
+      for (int w = 0; w < 3; ++w) {
+        const float4 o = *reinterpret_cast<const float4*>(xo + ((static_cast<size_t>(w) * MTQ + mt) * 16 + c16) * kD + dt * 16 + 4 * g);
+        acc.x += o.x;
+        acc.y += o.y;
+        acc.z += o.z;
+        acc.w += o.w;
+      }
+      *reinterpret_cast<float4*>(op + dt * 16) = acc;
+    }
     if (g == 0) {
-      float* mp = P.ws_ml + (static_cast<int64_t>(part) * P.total_rows + grow) * 2;
-      mp[0] = m_run[mt];
-      mp[1] = l_run[mt];
+      float* mp = P.ws_ml + (static_cast<int64_t>(bpart) * P.total_rows + grow) * 2;
+      mp[0] = m_all[mt];
+      mp[1] = l_all[mt];
     }
   }
 }
@@ -339,7 +412,7 @@ extern "C" {
 
 size_t aic_verify_attention_workspace_bytes(int num_tokens, int num_q_heads, int head_size, int num_splits_max) {
   const size_t rows = static_cast<size_t>(num_tokens) * num_q_heads;
-  const size_t parts = static_cast<size_t>(num_splits_max > 0 ? num_splits_max : 64) * 4;
+  const size_t parts = static_cast<size_t>(num_splits_max > 0 ? num_splits_max : 64);
   return parts * rows * (static_cast<size_t>(head_size) + 2) * sizeof(float) + 256;
 }
 
@@ -382,8 +455,8 @@ int aic_verify_attention(const void* q, int64_t q_stride, const void* k_cache, c
   const int m_groups = (max_rows + mtq * 16 - 1) / (mtq * 16);
   int n_splits = pick_splits(batch, num_kv_heads, 1, max_seq_len);
   const size_t rows = static_cast<size_t>(num_tokens) * num_q_heads;
-  while (n_splits > 1 && static_cast<size_t>(n_splits) * 4 * rows * (kD + 2) * sizeof(float) > workspace_bytes) --n_splits;
-  AIC_REQUIRE(static_cast<size_t>(n_splits) * 4 * rows * (kD + 2) * sizeof(float) <= workspace_bytes,
+  while (n_splits > 1 && static_cast<size_t>(n_splits) * rows * (kD + 2) * sizeof(float) > workspace_bytes) --n_splits;
+  AIC_REQUIRE(static_cast<size_t>(n_splits) * rows * (kD + 2) * sizeof(float) <= workspace_bytes,
               "workspace too small (%zu bytes)", workspace_bytes);
 
   AttnParams P;
@@ -394,7 +467,7 @@ int aic_verify_attention(const void* q, int64_t q_stride, const void* k_cache, c
   P.seq_lens = seq_lens;
   P.query_start_loc = query_start_loc;
   P.ws_o = static_cast<float*>(workspace);
-  P.ws_ml = P.ws_o + static_cast<size_t>(n_splits) * 4 * rows * kD;
+  P.ws_ml = P.ws_o + static_cast<size_t>(n_splits) * rows * kD;
   P.q_stride = q_stride;
   P.block_stride = block_stride;
   P.max_blocks = max_blocks_per_seq;
@@ -416,7 +489,7 @@ int aic_verify_attention(const void* q, int64_t q_stride, const void* k_cache, c
   int rc = launch_status("verify_attn_kernel");
   if (rc != AIC_OK) return rc;
   hipLaunchKernelGGL(verify_attn_combine_kernel, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s, P.ws_o,
-                     P.ws_ml, n_splits * 4, static_cast<int>(rows), num_q_heads, static_cast<uint16_t*>(out), out_stride);
+                     P.ws_ml, n_splits, static_cast<int>(rows), num_q_heads, static_cast<uint16_t*>(out), out_stride);
   return launch_status("verify_attn_combine_kernel");
 }
 
