@@ -1,0 +1,3 @@
+from arcticinference_amd.suffix_cache import SuffixCache, SuffixSpecResult  # noqa: F401
+
+__all__ = ["SuffixCache", "SuffixSpecResult"]

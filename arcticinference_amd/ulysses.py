@@ -1,0 +1,246 @@
+"""Ulysses sequence parallelism + shift parallelism, host side.
+
+Reference: /root/reference/arctic_inference/vllm/ulysses.py
+  * process-group layout  ExternalDP x DP x PP x SP x TP            (:150-281)  -> rank_groups()
+  * head counts per rank, KV replication when Hkv < SP               (:56-105, :432-455) -> local_heads()
+  * attention wrapper: pack -> all-to-all -> attention -> all-to-all -> unpack   (:457-519) -> UlyssesAttention
+  * shift parallelism: below a token threshold run the TP = SP*TP replica instead (model_runner.py:57-81,
+    :237-247); both layouts own the same KV-cache head slice ("KV-cache invariance")
+    -> use_shift_model(), sp_tp_head_slice()
+
+MI355X notes.  One process per GPU; the collectives are torch.distributed calls, i.e. RCCL over xGMI.  The
+two dominant collectives are equal-split all-to-alls, which map 1:1 onto the fully connected xGMI mesh
+(each peer message rides its own link), so they are issued as single `all_to_all_single` calls on
+contiguous buffers; the copies around them are ONE fused HIP kernel each (csrc/ulysses_pack.hip) that
+writes the send layout / reads the receive layout directly, and the attention kernel consumes q straight
+out of the receive buffer through a token stride — the reference's split() views cost nothing here
+either, but its cat/transpose/reshape chains (3-4 copy kernels per layer) are gone.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+
+# --------------------------------------------------------------------------------------------------
+# group algebra (pure; tested on CPU)
+# --------------------------------------------------------------------------------------------------
+def rank_groups(world_size: int, dp: int, pp: int, sp: int, tp: int, num_kv_heads: Optional[int] = None
+                ) -> Dict[str, List[List[int]]]:
+    """Rank lists of every group the reference creates (ulysses.py:160-281).  Global rank of coordinate
+    (e, d, p, s, t) is ((((e*dp + d)*pp + p)*sp + s)*tp + t): TP fastest, then SP."""
+    assert world_size % (dp * pp * sp * tp) == 0
+    ext = world_size // (dp * pp * sp * tp)
+    dims = (ext, dp, pp, sp, tp)
+
+    def rank(e, d, p, s, t):
+        return (((e * dp + d) * pp + p) * sp + s) * tp + t
+
+    def groups(vary: Tuple[int, ...], order: Optional[Tuple[int, ...]] = None):
+        """All groups obtained by varying the axes in `vary` (iteration order `order`, last fastest)."""
+        order = order or vary
+        fixed = [a for a in range(5) if a not in vary]
+        out = []
+
+        def rec_fixed(i, coord):
+            if i == len(fixed):
+                members = []
+
+                def rec_vary(j, c):
+                    if j == len(order):
+                        members.append(rank(*c))
+                        return
+                    ax = order[j]
+                    for v in range(dims[ax]):
+                        c2 = list(c)
+                        c2[ax] = v
+                        rec_vary(j + 1, c2)
+                rec_vary(0, list(coord))
+                out.append(members)
+                return
+            ax = fixed[i]
+            for v in range(dims[ax]):
+                c2 = list(coord)
+                c2[ax] = v
+                rec_fixed(i + 1, c2)
+        rec_fixed(0, [0] * 5)
+        return out
+
+    g = {
+        "TP": groups((4,)),
+        "PP": groups((2,)),
+        "DP": groups((1,)),
+        "EP": groups((1, 4)),          # DP x TP (ulysses.py:200-207)
+        "SP": groups((3,)),
+        # full-TP group of shift parallelism: TP-major / SP-minor member order ("transpose(3, 4) for the
+        # correct attn head order", :225-229): index in group = t * SP + s
+        "SP_TP": groups((3, 4), order=(4, 3)),
+    }
+    if num_kv_heads is not None and num_kv_heads < sp:
+        # KV-replicated variant (:251-281): SP = SP_AA (size Hkv, all-to-all of kv heads) x SP_AG (all-gather)
+        aa, ag = num_kv_heads, sp // num_kv_heads
+        assert aa * ag == sp
+        sp_aa, sp_ag = [], []
+        for e in range(ext):
+            for d in range(dp):
+                for p in range(pp):
+                    for t in range(tp):
+                        for j in range(ag):
+                            sp_aa.append([rank(e, d, p, i * ag + j, t) for i in range(aa)])
+                        for i in range(aa):
+                            sp_ag.append([rank(e, d, p, i * ag + j, t) for j in range(ag)])
+        g["SP_AA"], g["SP_AG"] = sp_aa, sp_ag
+    return g
+
+
+@dataclass
+class LocalHeads:
+    num_q_heads: int
+    num_kv_heads: int
+    kv_replicated: bool
+
+
+def local_heads(num_q_heads: int, num_kv_heads: int, sp: int, tp: int = 1, shift_mode: bool = False) -> LocalHeads:
+    """Heads a rank owns inside attention.  SP mode divides by SP after TP (:432-455); shift mode is a plain
+    TP = SP*TP model.  Either way the rank reads the same KV-cache head slice."""
+    ways = sp * tp
+    q = num_q_heads // ways
+    if num_kv_heads >= ways:
+        return LocalHeads(q, num_kv_heads // ways, False)
+    return LocalHeads(q, 1, True)
+
+
+def use_shift_model(num_tokens: int, sp: int, enable_shift_parallel: bool, threshold: int = 512) -> bool:
+    """model_runner.py:237-239."""
+    return sp > 1 and enable_shift_parallel and num_tokens <= threshold
+
+
+def pad_tokens_for_sp(num_tokens: int, sp: int) -> int:
+    """Tokens are rounded up to a multiple of SP before being split across ranks (model_runner.py:240-247)."""
+    return (num_tokens + sp - 1) // sp * sp
+
+
+def sp_tp_head_slice(num_heads: int, sp: int, tp: int, sp_rank: int, tp_rank: int) -> Tuple[int, int]:
+    """[first, last) q-head range owned by (tp_rank, sp_rank): TP-major / SP-minor, identical for the SP
+    layout and for the shift (TP over SP_TP) layout — the KV-cache invariance the shift model relies on."""
+    per = num_heads // (sp * tp)
+    idx = tp_rank * sp + sp_rank
+    return idx * per, (idx + 1) * per
+
+
+# --------------------------------------------------------------------------------------------------
+# attention wrapper
+# --------------------------------------------------------------------------------------------------
+def _hip_pack(q, k, v, sp):
+    from . import ops
+    return ops.ulysses_pack_qkv(q, k, v, sp)
+
+
+def _hip_unpack(c, sp):
+    from . import ops
+    return ops.ulysses_unpack_out(c, sp)
+
+
+class UlyssesAttention:
+    """pack -> all-to-all -> `attn` on (all tokens x local heads) -> all-to-all -> unpack (ulysses.py:491-519).
+
+    `attn(q_, k_, v_)` receives strided views into the receive buffer: q_ [N, hq*D], k_/v_ [N, hkv*D] with
+    row stride (hq + 2 hkv) * D, and returns [N, hq*D] contiguous.  `pack` / `unpack` default to the HIP
+    kernels; the CPU (gloo) tests inject torch expressions so the group / index logic runs without a GPU."""
+
+    def __init__(self, sp_size: int, group, num_q_heads_local: int, num_kv_heads_local: int, head_size: int,
+                 pack: Callable = _hip_pack, unpack: Callable = _hip_unpack):
+        self.sp_size, self.group = sp_size, group
+        self.hq, self.hkv, self.D = num_q_heads_local, num_kv_heads_local, head_size
+        self.pack, self.unpack = pack, unpack
+
+    def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, attn: Callable) -> torch.Tensor:
+        import torch.distributed as dist
+        if self.sp_size == 1:
+            return attn(query, key, value)
+        qw, kw = self.hq * self.D, self.hkv * self.D
+        send = self.pack(query, key, value, self.sp_size)               # [SP*n, qw + 2kw], rank-major
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)            # C1 (ulysses.py:502)
+        q_, k_, v_ = recv[:, :qw], recv[:, qw:qw + kw], recv[:, qw + kw:]
+        c_ = attn(q_, k_, v_)                                           # all N tokens, local heads
+        c = torch.empty_like(c_)
+        dist.all_to_all_single(c, c_, group=self.group)                 # C2 (ulysses.py:514)
+        return self.unpack(c, self.sp_size)                             # [n, SP*qw]
+
+
+class UlyssesContext:
+    """SP state of one rank for the stand-alone engine (arcticinference_amd/engine.py): the per-layer
+    attention of a step runs on this rank's head slice with the two all-to-alls around it."""
+
+    def __init__(self, sp_size: int, sp_rank: int, group, shape, device="cuda"):
+        self.sp_size, self.sp_rank, self.group = sp_size, sp_rank, group
+        lh = local_heads(shape.num_q_heads, shape.num_kv_heads, sp_size)
+        if lh.kv_replicated:
+            raise NotImplementedError("KV-replicated Ulysses (Hkv < SP) is not on the MI355X path yet (SURVEY §8f-3)")
+        self.heads = lh
+        self.attn = UlyssesAttention(sp_size, group, lh.num_q_heads, lh.num_kv_heads, shape.head_size)
+
+    def attention_layers(self, eng, T, bt, d_seq, d_qsl, max_q, max_ctx) -> None:
+        from . import ops
+        s = eng.shape
+        sp = self.sp_size
+        Tp = pad_tokens_for_sp(T, sp)
+        n = Tp // sp
+        lo = self.sp_rank * n
+        D = s.head_size
+        hq, hkv = self.heads.num_q_heads, self.heads.num_kv_heads
+        # this rank's token slice x all heads, as the dense layers of the target would hand it over
+        q = eng.q_buf[lo:lo + n]
+        k = eng.k_buf[lo:lo + n]
+        v = eng.v_buf[lo:lo + n]
+
+        def attn(q_, k_, v_, layer):
+            kv = eng.kv[layer]
+            out = eng.attn_out[:Tp].view(Tp, hq, D)
+            qv = q_.unflatten(1, (hq, D))   # strided view into the all-to-all receive buffer
+            ops.verify_attention(qv[:T], kv[0], kv[1], bt, d_seq, d_qsl, max_q, max_ctx, eng.sm_scale, out=out[:T])
+            return eng.attn_out[:Tp]
+
+        for layer in range(s.num_layers):
+            self.attn.forward(q, k, v, lambda a, b, c, L=layer: attn(a, b, c, L))
+
+
+# --------------------------------------------------------------------------------------------------
+# vLLM patches (built only when vLLM is importable)
+# --------------------------------------------------------------------------------------------------
+def build_ulysses_patches():
+    """ArcticPatch classes for vllm.attention.layer.Attention and ModelConfig head counts.  The executor /
+    parallel_state patches of the reference (ulysses.py:107-424) are process-management code outside the
+    hot path and are not rebuilt here; with them absent the plugin supports SP only when vLLM itself is
+    launched with a world of PP*TP*SP workers by an external launcher."""
+    from vllm.attention.layer import Attention
+    from vllm.distributed import parallel_state
+
+    from .patching import ArcticPatch
+
+    class UlyssesAttentionPatch(ArcticPatch[Attention]):
+        _orig_init = Attention.__init__
+        _orig_forward = Attention.forward
+
+        def __init__(self, num_heads, *args, **kwargs):
+            sp = getattr(parallel_state, "_SP", None)
+            self.sp_size = sp.world_size if sp is not None else 1
+            self.sp_device_group = sp.device_group if sp is not None else None
+            if self.sp_size > 1:
+                lh = local_heads(num_heads * 1, kwargs["num_kv_heads"], self.sp_size)
+                if lh.kv_replicated:
+                    raise NotImplementedError("KV-replicated Ulysses is not supported by this build")
+                num_heads //= self.sp_size
+                kwargs["num_kv_heads"] = lh.num_kv_heads
+            return self._orig_init(num_heads, *args, **kwargs)
+
+        def forward(self, query, key, value, **kwargs):
+            if self.sp_size == 1:
+                return self._orig_forward(query, key, value, **kwargs)
+            ua = UlyssesAttention(self.sp_size, self.sp_device_group, self.num_heads, self.num_kv_heads, self.head_size)
+            return ua.forward(query, key, value, lambda q_, k_, v_: self._orig_forward(q_, k_, v_, **kwargs))
+
+    return [UlyssesAttentionPatch]

@@ -1,0 +1,51 @@
+"""Entry point `arctic_inference.vllm.plugins:arctic_inference_plugin` (vLLM entry-point group
+"vllm.general_plugins"; reference: /root/reference/arctic_inference/vllm/plugins.py:66-126).
+
+Deliberate deviation from the reference: its platform gate returns early unless `is_cuda()`
+(plugins.py:74-77), which disables the plugin on ROCm.  This build is for MI355X, so the gate accepts the
+ROCm platform (and CUDA-like platforms are refused: the native library is gfx950 only)."""
+from __future__ import annotations
+
+import logging
+import os
+
+logger = logging.getLogger(__name__)
+
+COMPATIBLE_VLLM_VERSION = "0.9.2"  # pyproject.toml:41-43 of the reference
+
+
+def arctic_inference_plugin() -> None:
+    try:
+        import vllm
+    except ImportError:
+        logger.warning("ArcticInference (MI355X build): vLLM is not installed. Ignoring plugin!")
+        return
+    if vllm.__version__ != COMPATIBLE_VLLM_VERSION and not vllm.__version__.startswith("0.1.dev"):
+        logger.warning("ArcticInference requires vllm==%s but found vllm==%s. Ignoring plugin!",
+                       COMPATIBLE_VLLM_VERSION, vllm.__version__)
+        return
+    from vllm.platforms import current_platform
+    if not current_platform.is_rocm():
+        logger.warning("ArcticInference (MI355X build) requires the ROCm platform. Ignoring plugin!")
+        return
+    if os.getenv("VLLM_USE_V1") == "0":
+        logger.warning("ArcticInference only supports vLLM V1, but detected V0 engine. Ignoring plugin!")
+        return
+    from .. import _native
+    if _native.lib().aic_device_count() <= 0:
+        raise RuntimeError("libarctic_hip.so found no HIP device; there is no CPU fallback")
+
+    from vllm import ModelRegistry
+    ModelRegistry.register_model("ArcticLSTMSpeculatorPreTrainedModel",
+                                 "arcticinference_amd.vllm_plugin.model_runner:ArcticLSTMSpeculatorForVllm")
+    ModelRegistry.register_model("MLPVariantSpeculatorPreTrainedModel",
+                                 "arcticinference_amd.vllm_plugin.model_runner:ArcticLSTMSpeculatorForVllm")
+
+    from .config import build_config_patches
+    from .model_runner import build_bootstrap_patches
+    from .stats import build_stats_patches
+    from ..ulysses import build_ulysses_patches
+
+    for patch in (build_bootstrap_patches() + build_config_patches() + build_stats_patches() +
+                  build_ulysses_patches()):
+        patch.apply_patch()

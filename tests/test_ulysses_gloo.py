@@ -1,0 +1,83 @@
+"""CPU, world_size 2 and 4 over gloo: the N>1 path of UlyssesAttention (pack -> all-to-all -> attention on
+local heads over ALL tokens -> all-to-all -> unpack) reproduces single-process attention over all heads.
+The HIP pack/unpack kernels cannot run here, so the test injects the oracle's torch expressions of
+ulysses.py:493-517 for those two copies; group logic, buffer shapes, strided q/k/v views and the
+collective sequence are the product's."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import spec_oracle as O
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, Hq, Hkv, D, N, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from arcticinference_amd.ulysses import UlyssesAttention, local_heads
+        g = torch.Generator().manual_seed(0)
+        q = torch.randn(N, Hq * D, generator=g)
+        k = torch.randn(N, Hkv * D, generator=g)
+        v = torch.randn(N, Hkv * D, generator=g)
+        lh = local_heads(Hq, Hkv, world)
+        hq, hkv = lh.num_q_heads, lh.num_kv_heads
+        n = N // world
+        sl = slice(rank * n, (rank + 1) * n)
+
+        def attn(q_, k_, v_):
+            # plain causal attention over all N tokens with this rank's heads (fp32); inputs are strided views
+            assert q_.shape == (N, hq * D) and k_.shape == (N, hkv * D)
+            Q = q_.reshape(N, hq, D).transpose(0, 1)
+            K = k_.reshape(N, hkv, D).transpose(0, 1).repeat_interleave(hq // hkv, 0)
+            V = v_.reshape(N, hkv, D).transpose(0, 1).repeat_interleave(hq // hkv, 0)
+            s = Q @ K.transpose(1, 2) / D ** 0.5
+            s = s.masked_fill(~torch.tril(torch.ones(N, N, dtype=torch.bool)), float("-inf"))
+            return (torch.softmax(s, -1) @ V).transpose(0, 1).reshape(N, hq * D).contiguous()
+
+        ua = UlyssesAttention(world, dist.group.WORLD, hq, hkv, D,
+                              pack=lambda a, b, c, sp: O.ulysses_pack(a, b, c, sp, hq, hkv, D),
+                              unpack=lambda c, sp: O.ulysses_unpack(c, sp, hq, D))
+        out = ua.forward(q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(), attn)
+        # single-process reference over all heads, then this rank's token slice
+        ref_all = UlyssesAttention(1, None, Hq, Hkv, D).forward(q, k, v, lambda a, b, c: _full(a, b, c, Hq, Hkv, D, N))
+        ok = torch.allclose(out, ref_all[sl], atol=1e-5)
+        out_q.put((rank, bool(ok), tuple(out.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _full(q, k, v, Hq, Hkv, D, N):
+    Q = q.reshape(N, Hq, D).transpose(0, 1)
+    K = k.reshape(N, Hkv, D).transpose(0, 1).repeat_interleave(Hq // Hkv, 0)
+    V = v.reshape(N, Hkv, D).transpose(0, 1).repeat_interleave(Hq // Hkv, 0)
+    s = Q @ K.transpose(1, 2) / D ** 0.5
+    s = s.masked_fill(~torch.tril(torch.ones(N, N, dtype=torch.bool)), float("-inf"))
+    return (torch.softmax(s, -1) @ V).transpose(0, 1).reshape(N, Hq * D)
+
+
+@pytest.mark.parametrize("world,Hq,Hkv", [(2, 8, 2), (4, 8, 4)])
+def test_ulysses_attention_gloo(world, Hq, Hkv):
+    ctx = mp.get_context("spawn")
+    qout = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, Hq, Hkv, 16, 8 * world, qout)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [qout.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
+    assert all(r[1] for r in res), res
+    assert all(r[2] == (8, Hq * 16) for r in res)
