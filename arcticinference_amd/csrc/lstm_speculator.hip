@@ -37,7 +37,7 @@ namespace aic {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-constexpr int kChunkSteps = 8;   // k-steps per LDS chunk (bf16: 8 x 32 k = 256; fp8: 8 x 64 k = 512)
+constexpr int kChunkSteps = 4;   // k-steps per chunk (bf16: 4 x 32 k = 128; fp8: 4 x 64 k = 256)
 constexpr int kRowsPerBlock = 64;  // 4 waves x one 16-row tile
 
 __device__ __forceinline__ float r(float x) { return round_bf16(x); }
@@ -53,13 +53,15 @@ __device__ __forceinline__ int64_t xunit_fp8(int m, int k16, int MT) {  // k16 =
 }
 
 // ---- block reductions --------------------------------------------------------------------------
-__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+__device__ __forceinline__ float block_sum(float v, float* sh) {  // sh: >= 16 floats
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  const int wave = threadIdx.x >> 6;
+  const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   __syncthreads();  // sh may still be read from a previous reduction
   if ((threadIdx.x & 63) == 0) sh[wave] = v;
   __syncthreads();
-  return sh[0] + sh[1] + sh[2] + sh[3];
+  float t = 0.0f;
+  for (int w = 0; w < n_waves; ++w) t += sh[w];
+  return t;
 }
 
 // ---- weight repacking (one-time, at load) ------------------------------------------------------
@@ -157,7 +159,7 @@ __global__ void __launch_bounds__(256)
 ln0_kernel(const uint16_t* __restrict__ hidden, const int32_t* __restrict__ hidden_index, int batch, int H, int MT,
            int scale_input, uint4* __restrict__ x_out, uint16_t* __restrict__ cell, int Ds,
            unsigned int* __restrict__ amax_bits, int n_amax) {
-  __shared__ float sh[4];
+  __shared__ float sh[16];
   const int m = blockIdx.x;
   if (m == 0 && threadIdx.x < n_amax) amax_bits[threadIdx.x] = 0u;
   // zero initial cell state (arctic_speculator.py:781-785)
@@ -180,7 +182,7 @@ ln0_kernel(const uint16_t* __restrict__ hidden, const int32_t* __restrict__ hidd
         ss += r(v * v);  // xf.pow(2) is a bf16 tensor
       }
     }
-    ss = block_sum_256(ss, sh);
+    ss = block_sum(ss, sh);
   }
   const float mean = r(ss / static_cast<float>(H));
   const float rs = r(rsqrtf(r(mean + 1e-6f)));
@@ -199,14 +201,22 @@ ln0_kernel(const uint16_t* __restrict__ hidden, const int32_t* __restrict__ hidd
 // ---- skinny GEMM: out[m][n] = sum_k X[m][k] * W[n][k],  M = 16*MT <= 64 ---------------------------
 // EPI 0: fp32 partials  part[split][m][n]          (gate projection, split-K over blockIdx.y)
 // EPI 1: arg-max of bf16(acc * scale) over the block's 64 rows -> best_val/best_idx[block][m]
+//
+// Pipeline: K is walked in chunks of S = 4 k-steps (4 KiB of weights per wave).  Weight fragments go
+// straight from HBM to VGPRs through a ring of FOUR register sets, three chunks (12 KiB per wave) ahead of
+// the MFMAs; with ~128 VGPRs four workgroups fit a CU, i.e. 16 waves x 12 KiB = 192 KiB of weight loads in
+// flight per CU — the kernel is latency-bound on HBM, not MFMA-bound, so bytes in flight are the lever
+// (one set, one chunk ahead measured 2.6 TB/s).  The activation chunk (L2 resident) is copied one chunk
+// ahead into a double-buffered LDS tile shared by the four waves; one barrier per chunk.  The register
+// sets are named scalars: kept as arrays the compiler demotes them to scratch at this occupancy.
 template <bool FP8, int MT, int EPI>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256)
 skinny_gemm_kernel(const uint4* __restrict__ W, const uint4* __restrict__ X, int n_rowtiles, int steps_total,
                    int steps_per_split, float* __restrict__ part, int n_cols_out, const float* __restrict__ x_scale,
                    float w_scale, int n_valid_rows, int row_offset, float* __restrict__ best_val,
                    int32_t* __restrict__ best_idx) {
   constexpr int S = kChunkSteps;
-  constexpr int XV = S * MT * 64 / 256;  // uint4 per thread per chunk
+  constexpr int XV = S * MT * 64 / 256;  // uint4 per thread per activation chunk ( = MT )
   __shared__ uint4 lds[2][S * MT * 64];
 
   const int tid = threadIdx.x;
@@ -224,67 +234,77 @@ skinny_gemm_kernel(const uint4* __restrict__ W, const uint4* __restrict__ X, int
 #pragma unroll
   for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  uint4 xr[XV];
-  uint4 a0[S], a1[S];
-#pragma unroll
-  for (int i = 0; i < XV; ++i) xr[i] = x_ptr[i * 256];
-#pragma unroll
-  for (int s = 0; s < S; ++s) a0[s] = a_ptr[s * 64];
-#pragma unroll
-  for (int i = 0; i < XV; ++i) lds[0][i * 256 + tid] = xr[i];
-  __syncthreads();
-
-  auto compute = [&](const uint4(&a)[S], int buf) {
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const uint4 b = lds[buf][(s * MT + mt) * 64 + lane];
-        if (FP8) {
-          const long a_lo = static_cast<long>(a[s].x) | (static_cast<long>(a[s].y) << 32);
-          const long a_hi = static_cast<long>(a[s].z) | (static_cast<long>(a[s].w) << 32);
-          const long b_lo = static_cast<long>(b.x) | (static_cast<long>(b.y) << 32);
-          const long b_hi = static_cast<long>(b.z) | (static_cast<long>(b.w) << 32);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a_lo, b_lo, acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a_hi, b_hi, acc[mt], 0, 0, 0);
-        } else {
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[s]),
-                                                            __builtin_bit_cast(bf16x8, b), acc[mt], 0, 0, 0);
-        }
-      }
-    }
-  };
-
-  // two chunks per trip so the weight prefetch ping-pongs between a0 / a1 without register copies
-  for (int c = 0; c < n_chunks; c += 2) {
-    const bool has1 = c + 1 < n_chunks;
-    if (has1) {
-#pragma unroll
-      for (int i = 0; i < XV; ++i) xr[i] = x_ptr[static_cast<int64_t>(c + 1) * S * MT * 64 + i * 256];
-#pragma unroll
-      for (int s = 0; s < S; ++s) a1[s] = a_ptr[(static_cast<int64_t>(c + 1) * S + s) * 64];
-    }
-    compute(a0, 0);
-    if (has1) {
-#pragma unroll
-      for (int i = 0; i < XV; ++i) lds[1][i * 256 + tid] = xr[i];
-    }
-    __syncthreads();
-    if (!has1) break;
-    const bool has2 = c + 2 < n_chunks;
-    if (has2) {
-#pragma unroll
-      for (int i = 0; i < XV; ++i) xr[i] = x_ptr[static_cast<int64_t>(c + 2) * S * MT * 64 + i * 256];
-#pragma unroll
-      for (int s = 0; s < S; ++s) a0[s] = a_ptr[(static_cast<int64_t>(c + 2) * S + s) * 64];
-    }
-    compute(a1, 1);
-    if (has2) {
-#pragma unroll
-      for (int i = 0; i < XV; ++i) lds[0][i * 256 + tid] = xr[i];
-    }
-    __syncthreads();
+  uint4 xr0, xr1, xr2, xr3;  // XV = MT <= 4 of them are live
+  (void)xr1; (void)xr2; (void)xr3;
+  uint4 a0_0, a0_1, a0_2, a0_3, a1_0, a1_1, a1_2, a1_3, a2_0, a2_1, a2_2, a2_3, a3_0, a3_1, a3_2, a3_3;
+#define AIC_LOAD_A(set_, c_)                                              \
+  {                                                                        \
+    const uint4* p_ = a_ptr + static_cast<int64_t>(c_) * S * 64;           \
+    set_##_0 = p_[0];                                                      \
+    set_##_1 = p_[64];                                                     \
+    set_##_2 = p_[128];                                                    \
+    set_##_3 = p_[192];                                                    \
   }
+#define AIC_LOAD_X(c_)                                                        \
+  {                                                                           \
+    const uint4* xp_ = x_ptr + static_cast<int64_t>(c_) * S * MT * 64;        \
+    xr0 = xp_[0];                                                             \
+    if (XV > 1) xr1 = xp_[256];                                               \
+    if (XV > 2) xr2 = xp_[512];                                               \
+    if (XV > 3) xr3 = xp_[768];                                               \
+  }
+#define AIC_STORE_X(buf_)                    \
+  {                                          \
+    lds[buf_][tid] = xr0;                    \
+    if (XV > 1) lds[buf_][256 + tid] = xr1;  \
+    if (XV > 2) lds[buf_][512 + tid] = xr2;  \
+    if (XV > 3) lds[buf_][768 + tid] = xr3;  \
+  }
+#define AIC_MMA_STEP(areg_, s_, buf_)                                                                             \
+  _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                             \
+    const uint4 b = lds[buf_][((s_) * MT + mt) * 64 + lane];                                                      \
+    if (FP8) {                                                                                                    \
+      const long a_lo = static_cast<long>(areg_.x) | (static_cast<long>(areg_.y) << 32);                          \
+      const long a_hi = static_cast<long>(areg_.z) | (static_cast<long>(areg_.w) << 32);                          \
+      const long b_lo = static_cast<long>(b.x) | (static_cast<long>(b.y) << 32);                                  \
+      const long b_hi = static_cast<long>(b.z) | (static_cast<long>(b.w) << 32);                                  \
+      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a_lo, b_lo, acc[mt], 0, 0, 0);                         \
+      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a_hi, b_hi, acc[mt], 0, 0, 0);                         \
+    } else {                                                                                                      \
+      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, areg_),                        \
+                                                        __builtin_bit_cast(bf16x8, b), acc[mt], 0, 0, 0);         \
+    }                                                                                                             \
+  }
+#define AIC_COMPUTE(set_, buf_) \
+  AIC_MMA_STEP(set_##_0, 0, buf_) AIC_MMA_STEP(set_##_1, 1, buf_) AIC_MMA_STEP(set_##_2, 2, buf_) AIC_MMA_STEP(set_##_3, 3, buf_)
+  // one pipeline stage: chunk c is computed from register set `cur_` and LDS buffer c & 1
+#define AIC_STAGE(c_, cur_, refill_)                                  \
+  if ((c_) < n_chunks) {                                               \
+    if ((c_) + 1 < n_chunks) AIC_LOAD_X((c_) + 1)                      \
+    if ((c_) + 3 < n_chunks) AIC_LOAD_A(refill_, (c_) + 3)             \
+    AIC_COMPUTE(cur_, (c_) & 1)                                        \
+    if ((c_) + 1 < n_chunks) AIC_STORE_X(((c_) + 1) & 1)               \
+    __syncthreads();                                                   \
+  }
+
+  AIC_LOAD_X(0)
+  AIC_LOAD_A(a0, 0)
+  if (1 < n_chunks) AIC_LOAD_A(a1, 1)
+  if (2 < n_chunks) AIC_LOAD_A(a2, 2)
+  AIC_STORE_X(0)
+  __syncthreads();
+  for (int c = 0; c < n_chunks; c += 4) {
+    AIC_STAGE(c, a0, a3)
+    AIC_STAGE(c + 1, a1, a0)
+    AIC_STAGE(c + 2, a2, a1)
+    AIC_STAGE(c + 3, a3, a2)
+  }
+#undef AIC_STAGE
+#undef AIC_COMPUTE
+#undef AIC_MMA_STEP
+#undef AIC_STORE_X
+#undef AIC_LOAD_X
+#undef AIC_LOAD_A
 
   // accumulator layout (16x16): column (batch row) = lane & 15, weight row = (lane >> 4) * 4 + reg
   const int n0 = rt * 16 + (lane >> 4) * 4;
@@ -351,17 +371,17 @@ skinny_gemm_kernel(const uint4* __restrict__ W, const uint4* __restrict__ X, int
 // one workgroup per batch row; r() marks every place the reference materialises a bf16 tensor
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 lstm_cell_kernel(const float* __restrict__ part, int n_splits, int m_pad, int batch, const int32_t* __restrict__ tokens,
                  const uint16_t* __restrict__ emb, int vocab_rows, float alpha, const uint16_t* __restrict__ cln_w,
                  const uint16_t* __restrict__ cln_b, const uint16_t* __restrict__ sln_w,
                  const uint16_t* __restrict__ sln_b, uint16_t* __restrict__ cell, int Ds, int MT,
                  uint4* __restrict__ h_out, unsigned int* __restrict__ amax_bits) {
   extern __shared__ float smem[];  // [Ds] staging of the row between the two normalisations
-  __shared__ float sh[4];
+  __shared__ float sh[16];
   const int m = blockIdx.x;
   if (m >= batch) {
-    for (int k8 = threadIdx.x; k8 < Ds / 8; k8 += 256) h_out[xunit_bf16(m, k8, MT)] = make_uint4(0, 0, 0, 0);
+    for (int k8 = threadIdx.x; k8 < Ds / 8; k8 += blockDim.x) h_out[xunit_bf16(m, k8, MT)] = make_uint4(0, 0, 0, 0);
     return;
   }
   const int N = 4 * Ds;
@@ -378,17 +398,17 @@ lstm_cell_kernel(const float* __restrict__ part, int n_splits, int m_pad, int ba
 
   // pass 1: cell candidate pre-activation and its mean square
   float ss = 0.0f;
-  for (int j = threadIdx.x; j < Ds; j += 256) {
+  for (int j = threadIdx.x; j < Ds; j += blockDim.x) {
     const float c = added(3 * Ds + j, j);
     smem[j] = c;
     ss += r(c * c);
   }
-  ss = block_sum_256(ss, sh);
+  ss = block_sum(ss, sh);
   float rs = r(rsqrtf(r(r(ss / static_cast<float>(Ds)) + 1e-6f)));
 
   // pass 2: gates, new cell state, its mean square
   float ss2 = 0.0f;
-  for (int j = threadIdx.x; j < Ds; j += 256) {
+  for (int j = threadIdx.x; j < Ds; j += blockDim.x) {
     float y = r(smem[j] * rs);
     y = r(bf16_to_f32(cln_w[j]) * y);
     y = r(y + bf16_to_f32(cln_b[j]));
@@ -399,12 +419,12 @@ lstm_cell_kernel(const float* __restrict__ part, int n_splits, int m_pad, int ba
     smem[j] = cnew;
     ss2 += r(cnew * cnew);
   }
-  ss2 = block_sum_256(ss2, sh);
+  ss2 = block_sum(ss2, sh);
   rs = r(rsqrtf(r(r(ss2 / static_cast<float>(Ds)) + 1e-6f)));
 
   // pass 3: state = gelu(state_ln(cell)) * output gate, written fragment-major for the next GEMMs
   float amax = 0.0f;
-  for (int k8 = threadIdx.x; k8 < Ds / 8; k8 += 256) {
+  for (int k8 = threadIdx.x; k8 < Ds / 8; k8 += blockDim.x) {
     uint16_t h[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -563,7 +583,7 @@ static int run_head(aic_lstm* m, int head_index, hipStream_t s, int64_t* out_tok
                                0, nullptr, nullptr);
     if (rc != AIC_OK) return rc;
     // 2. cell update
-    hipLaunchKernelGGL(lstm_cell_kernel, dim3(mpad), dim3(256), Ds * sizeof(float), s, m->part, splits, mpad, B,
+    hipLaunchKernelGGL(lstm_cell_kernel, dim3(mpad), dim3(1024), Ds * sizeof(float), s, m->part, splits, mpad, B,
                        m->tokens, static_cast<const uint16_t*>(m->w.forget_emb), 0x7fffffff, m->alpha,
                        static_cast<const uint16_t*>(m->w.cell_ln_w), static_cast<const uint16_t*>(m->w.cell_ln_b),
                        static_cast<const uint16_t*>(m->w.state_ln_w), static_cast<const uint16_t*>(m->w.state_ln_b),

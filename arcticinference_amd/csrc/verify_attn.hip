@@ -67,7 +67,13 @@ __device__ __forceinline__ int v_tile_off(int t, int ch) {
   return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
 
-template <int MTQ>
+// WH (waves = heads): the four waves of a workgroup take four consecutive kv heads over the SAME token
+// range, so the workgroup reads 4 x 256 B = 1 KiB contiguous per token and the heads of a token are
+// fetched together (DRAM page locality: with one head per workgroup every 2 KiB token row was touched by
+// eight workgroups at eight different times).  !WH (Hkv not a multiple of 4, e.g. one kv head per rank under
+// SP=8, where rows are contiguous anyway): the four waves split the token range of one head and are merged
+// through LDS at the end.
+template <int MTQ, bool WH>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ == 1 ? 3 : 2, MTQ == 1 ? 3 : 2))) verify_attn_kernel(AttnParams P) {
   // per wave: one 32-token V tile (8 KiB); reused at the end for the cross-wave merge
   constexpr int kMergeU4 = (8 * MTQ * 16 + 3 * MTQ * 16 * kD) / 4;
@@ -79,7 +85,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ ==
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps loop control scalar
   const int g = lane >> 4, c16 = lane & 15;
   const int Hkv = P.num_kv_heads, Hq = P.num_q_heads, G = Hq / Hkv;
-  const int req = blockIdx.x / Hkv, h = blockIdx.x - req * Hkv;
+  const int hgroups = WH ? Hkv / 4 : Hkv;
+  const int req = blockIdx.x / hgroups;
+  const int h = WH ? (blockIdx.x - req * hgroups) * 4 + wave : blockIdx.x - req * hgroups;
   const int q0 = P.query_start_loc[req];
   const int q_len = P.query_start_loc[req + 1] - q0;
   const int ctx = P.seq_lens[req];
@@ -87,8 +95,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ ==
   const int row0 = blockIdx.z * (MTQ * 16);
   if (row0 >= n_rows) return;
 
-  const int n_parts = P.n_splits * 4;
-  const int part = blockIdx.y * 4 + wave;
+  const int n_parts = WH ? P.n_splits : P.n_splits * 4;
+  const int part = WH ? blockIdx.y : blockIdx.y * 4 + wave;
   const int tiles_total = (ctx + kTile - 1) / kTile;
   const int tiles_per_part = (tiles_total + n_parts - 1) / n_parts;
   const int t_begin = part * tiles_per_part * kTile;
@@ -297,6 +305,27 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ ==
 #undef AIC_V_ADDR
 #undef AIC_STORE_V
 
+  if (WH) {
+    // every wave owns its own head: its partial goes straight to the workspace
+#pragma unroll
+    for (int mt = 0; mt < MTQ; ++mt) {
+      if (!row_ok[mt]) continue;
+      const int rr = row0 + mt * 16 + c16;
+      const int pos = rr / G, gq = rr - pos * G;
+      const int64_t grow = static_cast<int64_t>(q0 + pos) * Hq + h * G + gq;
+      float* op = P.ws_o + (static_cast<int64_t>(blockIdx.y) * P.total_rows + grow) * kD + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt)
+        *reinterpret_cast<float4*>(op + dt * 16) =
+            make_float4(o_acc[mt][dt][0], o_acc[mt][dt][1], o_acc[mt][dt][2], o_acc[mt][dt][3]);
+      if (g == 0) {
+        float* mp = P.ws_ml + (static_cast<int64_t>(blockIdx.y) * P.total_rows + grow) * 2;
+        mp[0] = m_run[mt];
+        mp[1] = l_run[mt];
+      }
+    }
+    return;
+  }
   // ---- merge the four waves of the workgroup (they hold disjoint token ranges of the same rows) ------
   // through LDS, so one partial per workgroup and row goes to the workspace instead of four
   __syncthreads();  // every wave is done with its V tile: the LDS is free
@@ -393,11 +422,12 @@ verify_attn_combine_kernel(const float* __restrict__ ws_o, const float* __restri
   *reinterpret_cast<uint32_t*>(op) = packed;
 }
 
-static int pick_splits(int batch, int num_kv_heads, int m_groups, int max_seq_len) {
-  const int64_t base_waves = static_cast<int64_t>(batch) * num_kv_heads * m_groups * 4;
+static int pick_splits(int batch, int num_kv_heads, int m_groups, int max_seq_len, bool wave_heads) {
+  // waves per split: one per kv head (wave_heads) or four per kv head (token range split over the waves)
+  const int64_t base_waves = static_cast<int64_t>(batch) * num_kv_heads * m_groups * (wave_heads ? 1 : 4);
   int64_t s = (6144 + base_waves - 1) / base_waves;  // ~3 waves per SIMD chip-wide
   const int max_tiles = (max_seq_len + kTile - 1) / kTile;
-  const int64_t cap = std::max(1, (max_tiles + 7) / 8);  // at least ~2 tiles per wave
+  const int64_t cap = std::max(1, wave_heads ? (max_tiles + 1) / 2 : (max_tiles + 7) / 8);  // >= ~2 tiles per wave
   if (s > cap) s = cap;
   if (s > 64) s = 64;
   if (s < 1) s = 1;
@@ -453,7 +483,8 @@ int aic_verify_attention(const void* q, int64_t q_stride, const void* k_cache, c
   const int avg_rows = (num_tokens + batch - 1) / batch * G;
   const int mtq = (max_rows <= 16 || avg_rows <= 24) ? 1 : 2;
   const int m_groups = (max_rows + mtq * 16 - 1) / (mtq * 16);
-  int n_splits = pick_splits(batch, num_kv_heads, 1, max_seq_len);
+  const bool wave_heads = num_kv_heads % 4 == 0;
+  int n_splits = pick_splits(batch, num_kv_heads, 1, max_seq_len, wave_heads);
   const size_t rows = static_cast<size_t>(num_tokens) * num_q_heads;
   while (n_splits > 1 && static_cast<size_t>(n_splits) * rows * (kD + 2) * sizeof(float) > workspace_bytes) --n_splits;
   AIC_REQUIRE(static_cast<size_t>(n_splits) * rows * (kD + 2) * sizeof(float) <= workspace_bytes,
@@ -479,12 +510,16 @@ int aic_verify_attention(const void* q, int64_t q_stride, const void* k_cache, c
   P.sm_scale = sm_scale;
 
   hipStream_t s = static_cast<hipStream_t>(stream);
-  dim3 grid(batch * num_kv_heads, n_splits, m_groups);
+  dim3 grid(batch * (wave_heads ? num_kv_heads / 4 : num_kv_heads), n_splits, m_groups);
   profile_begin(s);
-  if (mtq == 1)
-    hipLaunchKernelGGL(verify_attn_kernel<1>, grid, dim3(256), 0, s, P);
+  if (mtq == 1 && wave_heads)
+    hipLaunchKernelGGL((verify_attn_kernel<1, true>), grid, dim3(256), 0, s, P);
+  else if (mtq == 1)
+    hipLaunchKernelGGL((verify_attn_kernel<1, false>), grid, dim3(256), 0, s, P);
+  else if (wave_heads)
+    hipLaunchKernelGGL((verify_attn_kernel<2, true>), grid, dim3(256), 0, s, P);
   else
-    hipLaunchKernelGGL(verify_attn_kernel<2>, grid, dim3(256), 0, s, P);
+    hipLaunchKernelGGL((verify_attn_kernel<2, false>), grid, dim3(256), 0, s, P);
   profile_end(s);
   int rc = launch_status("verify_attn_kernel");
   if (rc != AIC_OK) return rc;

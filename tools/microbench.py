@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Per-kernel timings on the GPU box (not part of the bench contract; used while tuning)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from arcticinference_amd import ops
+from arcticinference_amd import _native as N
+
+dev = "cuda"
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+
+def attn(B=64, ctx=4096, qlen=4, Hq=32, Hkv=8, D=128, bs=16, layers=4):
+    nblk = (ctx + bs - 1) // bs
+    nb = B * nblk
+    kvs = [torch.randn(2, nb, bs, Hkv, D, device=dev, dtype=torch.bfloat16) for _ in range(layers)]
+    bt = torch.randperm(nb, device=dev).to(torch.int32).view(B, nblk)
+    T = B * qlen
+    q = torch.randn(T, Hq, D, device=dev, dtype=torch.bfloat16)
+    seq = torch.full((B,), ctx, dtype=torch.int32, device=dev)
+    qsl = (torch.arange(B + 1, device=dev) * qlen).to(torch.int32)
+    out = torch.empty_like(q)
+    i = [0]
+
+    def f():
+        kv = kvs[i[0] % layers]
+        i[0] += 1
+        ops.verify_attention(q, kv[0], kv[1], bt, seq, qsl, qlen, ctx, D ** -0.5, out=out)
+    us = timeit(f)
+    gb = B * ctx * 2 * Hkv * D * 2 / 1e9
+    print(f"attn B={B} ctx={ctx} qlen={qlen} Hq={Hq} Hkv={Hkv}: {us:8.1f} us  {gb / us * 1e6 / 1e3:6.2f} TB/s (incl. combine)")
+
+
+def lstm(B, fp8=True):
+    from arcticinference_amd.speculator import ArcticLSTMSpeculator, LSTMSpeculatorConfig, random_lstm_weights
+    cfg = LSTMSpeculatorConfig(vocab_size=128256, input_hidden_dim=4096)
+    m = ArcticLSTMSpeculator(cfg, max_num_seqs=64, device=dev, quantize_lm_head=fp8)
+    m.load_weights(random_lstm_weights(cfg, seed=0).items())
+    hid = torch.randn(B, 4096, device=dev, dtype=torch.bfloat16)
+    ids = torch.randint(0, 128256, (B,), device=dev)
+    us = timeit(lambda: m.generate_proposals(ids, hid, 3), iters=10)
+    head_gb = 128256 * 4096 * (1 if (fp8 and B <= 32) else 2) / 1e9
+    gate_gb = 4 * 4096 * 4096 * 2 / 1e9
+    print(f"lstm B={B} fp8={fp8 and B <= 32}: {us:8.1f} us per 3-head propose; weights {3 * (head_gb + gate_gb):.2f} GB -> "
+          f"{3 * (head_gb + gate_gb) / us * 1e6 / 1e3:5.2f} TB/s")
+    del m
+    torch.cuda.empty_cache()
+
+
+def rejection(B=64, k=3, V=128256):
+    logits = torch.randn(B * k, V, device=dev, dtype=torch.bfloat16)
+    draft = torch.randint(0, V, (B * k,), device=dev, dtype=torch.int32)
+    cu = (torch.arange(1, B + 1, device=dev) * k).to(torch.int32)
+    bonus = torch.zeros(B, dtype=torch.int32, device=dev)
+    us = timeit(lambda: ops.rejection_sample(logits, draft, cu, bonus, k))
+    print(f"rejection B={B} k={k}: {us:8.1f} us  {B * k * V * 2 / 1e9 / us * 1e6 / 1e3:5.2f} TB/s")
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["attn", "lstm", "rej"]
+    if "attn" in what:
+        attn()
+        attn(B=32)
+        attn(B=8)
+        attn(B=64, Hq=4, Hkv=1)        # SP=8 slice
+        attn(B=64, qlen=8)
+    if "lstm" in what:
+        lstm(64)
+        lstm(32)
+        lstm(8)
+    if "rej" in what:
+        rejection()
