@@ -55,6 +55,9 @@ struct AttnParams {
   int block_size;
   int n_splits;
   int total_rows;  // T * Hq
+  int m_groups;    // row groups of MTQ*16 query rows (folded into blockIdx.x)
+  int n_items;     // requests of this launch * head groups
+  const int32_t* req_list;  // request ids of this launch (device) or nullptr = identity
   float sm_scale;
 };
 
@@ -86,13 +89,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ ==
   const int g = lane >> 4, c16 = lane & 15;
   const int Hkv = P.num_kv_heads, Hq = P.num_q_heads, G = Hq / Hkv;
   const int hgroups = WH ? Hkv / 4 : Hkv;
-  const int req = blockIdx.x / hgroups;
-  const int h = WH ? (blockIdx.x - req * hgroups) * 4 + wave : blockIdx.x - req * hgroups;
+  // blockIdx.x = ((item / 8) * m_groups + row_group) * 8 + item % 8: the row groups of one (request, heads)
+  // item are dispatched back to back AND on the same XCD (workgroups are dealt round-robin over the 8 XCDs),
+  // so the extra row groups of a long (suffix) draft re-read their KV through that XCD's L2 instead of HBM;
+  // the row groups a short request does not have exit below after two scalar loads.
+  const int m_groups = P.m_groups;
+  const int item = (blockIdx.x / (8 * m_groups)) * 8 + (blockIdx.x & 7);
+  const int row_group = (blockIdx.x >> 3) % m_groups;
+  if (item >= P.n_items) return;
+  const int ridx = item / hgroups;
+  const int req = P.req_list ? P.req_list[ridx] : ridx;
+  const int h = WH ? (item - ridx * hgroups) * 4 + wave : item - ridx * hgroups;
   const int q0 = P.query_start_loc[req];
   const int q_len = P.query_start_loc[req + 1] - q0;
   const int ctx = P.seq_lens[req];
   const int n_rows = q_len * G;
-  const int row0 = blockIdx.z * (MTQ * 16);
+  const int row0 = row_group * (MTQ * 16);
   if (row0 >= n_rows) return;
 
   const int n_parts = WH ? P.n_splits : P.n_splits * 4;
@@ -394,6 +406,213 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ ==
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Long-draft variant (suffix drafts: up to 33 query positions = 132 rows at G = 4).  The four waves of a
+// workgroup stream the SAME tokens of ONE kv head; the 32-token K/V tile is loaded once per workgroup
+// (row-contiguous, 16 B per lane) into a double-buffered LDS image and every wave runs its own row tiles
+// (wave w owns row tiles w, w+4, w+8 -> up to 192 rows per workgroup) against it, so the KV bytes of a long
+// request are read once instead of once per row group.  One barrier per tile.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kLongTilesPerWave = 3;
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) verify_attn_long_kernel(AttnParams P) {
+  constexpr int RT = kLongTilesPerWave;
+  __shared__ uint4 kv_lds[2][2][kTile * 16];  // [buffer][K|V][32 tokens x 16 chunks]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c16 = lane & 15;
+  const int Hkv = P.num_kv_heads, Hq = P.num_q_heads, G = Hq / Hkv;
+  const int ridx = blockIdx.x / Hkv;
+  const int h = blockIdx.x - ridx * Hkv;
+  const int req = P.req_list ? P.req_list[ridx] : ridx;
+  const int q0 = P.query_start_loc[req];
+  const int q_len = P.query_start_loc[req + 1] - q0;
+  const int ctx = P.seq_lens[req];
+  const int n_rows = q_len * G;
+  const int row_base = blockIdx.z * (4 * RT * 16);  // row groups of 192 rows (only for G x q_len > 192)
+  if (row_base >= n_rows) return;
+
+  const int tiles_total = (ctx + kTile - 1) / kTile;
+  const int tiles_per_part = (tiles_total + P.n_splits - 1) / P.n_splits;
+  const int t_begin = blockIdx.y * tiles_per_part * kTile;
+  const int t_end = min(ctx, t_begin + tiles_per_part * kTile);
+
+  const int64_t kv_row = static_cast<int64_t>(Hkv) * kD;
+  const int32_t* btab = P.block_table + static_cast<int64_t>(req) * P.max_blocks;
+  const int bs = P.block_size;
+  const int last_group = (ctx - 1) & ~15;
+
+  // query fragments of this wave's row tiles
+  uint4 qf[RT][4];
+  int row_pos[RT];
+  bool row_ok[RT];
+#pragma unroll
+  for (int mt = 0; mt < RT; ++mt) {
+    const int rr = row_base + (wave + 4 * mt) * 16 + c16;
+    row_ok[mt] = rr < n_rows;
+    const int rc = min(rr, n_rows - 1);
+    const int pos = rc / G, gq = rc - pos * G;
+    row_pos[mt] = pos;
+    const uint16_t* qp = P.q + static_cast<int64_t>(q0 + pos) * P.q_stride + static_cast<int64_t>(h * G + gq) * kD + 8 * g;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[mt][s] = *reinterpret_cast<const uint4*>(qp + 32 * s);
+  }
+  float m_run[RT], l_run[RT];
+  f32x4 o_acc[RT][8];
+#pragma unroll
+  for (int mt = 0; mt < RT; ++mt) {
+    m_run[mt] = -INFINITY;
+    l_run[mt] = 0.0f;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) o_acc[mt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // cooperative tile load: thread t moves chunks t and t + 256 of K and of V (token = chunk / 16)
+  const int tk0 = threadIdx.x >> 4, tk1 = tk0 + 16, ch = threadIdx.x & 15;
+  uint4 rk0, rk1, rv0, rv1;
+#define AIC_LONG_LOAD(tt_)                                                                                      \
+  {                                                                                                             \
+    const int f0_ = min((tt_), last_group), f1_ = min((tt_) + 16, last_group);                                  \
+    const int64_t b0_ = static_cast<int64_t>(btab[f0_ / bs]) * P.block_stride + static_cast<int64_t>(f0_ % bs) * kv_row + h * kD; \
+    const int64_t b1_ = static_cast<int64_t>(btab[f1_ / bs]) * P.block_stride + static_cast<int64_t>(f1_ % bs) * kv_row + h * kD; \
+    const int64_t o0_ = b0_ + static_cast<int64_t>(min((tt_) + tk0, ctx - 1) - f0_) * kv_row + 8 * ch;         \
+    const int64_t o1_ = b1_ + static_cast<int64_t>(min((tt_) + tk1, ctx - 1) - f1_) * kv_row + 8 * ch;         \
+    rk0 = *reinterpret_cast<const uint4*>(P.k_cache + o0_);                                                     \
+    rk1 = *reinterpret_cast<const uint4*>(P.k_cache + o1_);                                                     \
+    rv0 = *reinterpret_cast<const uint4*>(P.v_cache + o0_);                                                     \
+    rv1 = *reinterpret_cast<const uint4*>(P.v_cache + o1_);                                                     \
+  }
+#define AIC_LONG_STORE(buf_)                                                                                    \
+  {                                                                                                             \
+    char* kb_ = reinterpret_cast<char*>(kv_lds[buf_][0]);                                                       \
+    char* vb_ = reinterpret_cast<char*>(kv_lds[buf_][1]);                                                       \
+    *reinterpret_cast<uint4*>(kb_ + v_tile_off(tk0, ch)) = rk0;                                                 \
+    *reinterpret_cast<uint4*>(kb_ + v_tile_off(tk1, ch)) = rk1;                                                 \
+    *reinterpret_cast<uint4*>(vb_ + v_tile_off(tk0, ch)) = rv0;                                                 \
+    *reinterpret_cast<uint4*>(vb_ + v_tile_off(tk1, ch)) = rv1;                                                 \
+  }
+
+  if (t_begin < t_end) {
+    AIC_LONG_LOAD(t_begin)
+    AIC_LONG_STORE(0)
+    __syncthreads();
+    int buf = 0;
+    for (int tt = t_begin; tt < t_end; tt += kTile, buf ^= 1) {
+      AIC_LONG_LOAD(tt + kTile)  // clamped into the context: always valid; unused past the range
+      const char* kb = reinterpret_cast<const char*>(kv_lds[buf][0]);
+      const char* vb = reinterpret_cast<const char*>(kv_lds[buf][1]);
+      // K fragments of the tile (A operand of S^T = K Q^T): lane (token c16 [+16], d = 32 s + 8 g)
+      uint4 kf[2][4];
+#pragma unroll
+      for (int th = 0; th < 2; ++th)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kf[th][s] = *reinterpret_cast<const uint4*>(kb + v_tile_off(16 * th + c16, 4 * s + g));
+
+      bf16x8 pfrag[RT], pfrag_lo[RT];
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt) {
+        f32x4 st[2];
+#pragma unroll
+        for (int th = 0; th < 2; ++th) {
+          st[th] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            st[th] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[th][s]),
+                                                             __builtin_bit_cast(bf16x8, qf[mt][s]), st[th], 0, 0, 0);
+        }
+        const int limit = ctx - q_len + row_pos[mt];
+        float sc[8];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int th = 0; th < 2; ++th)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int tok = tt + 16 * th + 4 * g + e;
+            const bool vis = row_ok[mt] && tok < t_end && tok <= limit;
+            const float v = vis ? st[th][e] * P.sm_scale : -INFINITY;
+            sc[th * 4 + e] = v;
+            tmax = fmaxf(tmax, v);
+          }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run[mt], tmax);
+        float alpha = 1.0f, psum = 0.0f;
+        float pv[8];
+        if (m_new == -INFINITY) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pv[e] = 0.0f;
+        } else {
+          alpha = __expf(m_run[mt] - m_new);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            pv[e] = __expf(sc[e] - m_new);
+            psum += pv[e];
+          }
+        }
+        psum += __shfl_xor(psum, 16);
+        psum += __shfl_xor(psum, 32);
+        l_run[mt] = l_run[mt] * alpha + psum;
+        m_run[mt] = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) o_acc[mt][dt] *= alpha;
+        bf16x8 pf, pl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          pf[e] = static_cast<__bf16>(pv[e]);
+          pl[e] = static_cast<__bf16>(pv[e] - static_cast<float>(pf[e]));
+        }
+        pfrag[mt] = pf;
+        pfrag_lo[mt] = pl;
+      }
+      {
+        const int q4 = c16 >> 2, p4 = c16 & 3;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+          const char* a_lo = vb + v_tile_off(4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
+          const char* a_hi = vb + v_tile_off(16 + 4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(a_lo)));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(a_hi)));
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          const bf16x8 vfrag = __builtin_bit_cast(bf16x8, both);
+#pragma unroll
+          for (int mt = 0; mt < RT; ++mt) {
+            o_acc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pfrag[mt], o_acc[mt][dt], 0, 0, 0);
+            o_acc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pfrag_lo[mt], o_acc[mt][dt], 0, 0, 0);
+          }
+        }
+      }
+      // next tile into the other buffer (its last readers finished before the previous barrier)
+      AIC_LONG_STORE(buf ^ 1)
+      __syncthreads();
+    }
+  }
+#undef AIC_LONG_LOAD
+#undef AIC_LONG_STORE
+
+#pragma unroll
+  for (int mt = 0; mt < RT; ++mt) {
+    if (!row_ok[mt]) continue;
+    const int rr = row_base + (wave + 4 * mt) * 16 + c16;
+    const int pos = rr / G, gq = rr - pos * G;
+    const int64_t grow = static_cast<int64_t>(q0 + pos) * Hq + h * G + gq;
+    float* op = P.ws_o + (static_cast<int64_t>(blockIdx.y) * P.total_rows + grow) * kD + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+      *reinterpret_cast<float4*>(op + dt * 16) =
+          make_float4(o_acc[mt][dt][0], o_acc[mt][dt][1], o_acc[mt][dt][2], o_acc[mt][dt][3]);
+    if (g == 0) {
+      float* mp = P.ws_ml + (static_cast<int64_t>(blockIdx.y) * P.total_rows + grow) * 2;
+      mp[0] = m_run[mt];
+      mp[1] = l_run[mt];
+    }
+  }
+}
+
 // one wavefront per output row (token, q head): merge the n_parts partials
 __global__ void __launch_bounds__(256)
 verify_attn_combine_kernel(const float* __restrict__ ws_o, const float* __restrict__ ws_ml, int n_parts, int total_rows,
@@ -446,12 +665,13 @@ size_t aic_verify_attention_workspace_bytes(int num_tokens, int num_q_heads, int
   return parts * rows * (static_cast<size_t>(head_size) + 2) * sizeof(float) + 256;
 }
 
-int aic_verify_attention(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
-                         int64_t block_stride, int kv_dtype, const float* k_scale, const float* v_scale,
-                         const int32_t* block_table, int max_blocks_per_seq, const int32_t* seq_lens,
-                         const int32_t* query_start_loc, int batch, int num_tokens, int max_q_len, int num_q_heads,
-                         int num_kv_heads, int head_size, int block_size, float sm_scale, void* out,
-                         int64_t out_stride, void* workspace, size_t workspace_bytes, int max_seq_len, void* stream) {
+int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
+                            int64_t block_stride, int kv_dtype, const float* k_scale, const float* v_scale,
+                            const int32_t* block_table, int max_blocks_per_seq, const int32_t* seq_lens,
+                            const int32_t* query_start_loc, int batch, int num_tokens, int max_q_len, int num_q_heads,
+                            int num_kv_heads, int head_size, int block_size, float sm_scale, void* out,
+                            int64_t out_stride, void* workspace, size_t workspace_bytes, int max_seq_len,
+                            const int32_t* short_reqs, int n_short, const int32_t* long_reqs, int n_long, void* stream) {
   if (batch == 0 || num_tokens == 0) return AIC_OK;
   AIC_REQUIRE(q && k_cache && v_cache && block_table && seq_lens && query_start_loc && out && workspace,
               "null pointer argument to aic_verify_attention");
@@ -459,6 +679,10 @@ int aic_verify_attention(const void* q, int64_t q_stride, const void* k_cache, c
                   max_blocks_per_seq > 0 && max_seq_len > 0,
               "non-positive size argument");
   AIC_REQUIRE(num_q_heads % num_kv_heads == 0, "num_q_heads must be a multiple of num_kv_heads");
+  const bool split_lists = short_reqs != nullptr || long_reqs != nullptr;
+  AIC_REQUIRE(!split_lists || (n_short >= 0 && n_long >= 0 && n_short + n_long == batch &&
+                               (n_short == 0 || short_reqs) && (n_long == 0 || long_reqs)),
+              "short/long request lists must partition the batch");
   (void)k_scale;
   (void)v_scale;
   if (head_size != kD) {
@@ -478,11 +702,6 @@ int aic_verify_attention(const void* q, int64_t q_stride, const void* k_cache, c
 
   const int G = num_q_heads / num_kv_heads;
   const int max_rows = max_q_len * G;
-  // rows per request in the common case decide the tile shape; the few long (suffix) drafts of a mixed
-  // batch take extra row groups instead of making every request pay for a two-tile kernel
-  const int avg_rows = (num_tokens + batch - 1) / batch * G;
-  const int mtq = (max_rows <= 16 || avg_rows <= 24) ? 1 : 2;
-  const int m_groups = (max_rows + mtq * 16 - 1) / (mtq * 16);
   const bool wave_heads = num_kv_heads % 4 == 0;
   int n_splits = pick_splits(batch, num_kv_heads, 1, max_seq_len, wave_heads);
   const size_t rows = static_cast<size_t>(num_tokens) * num_q_heads;
@@ -508,24 +727,65 @@ int aic_verify_attention(const void* q, int64_t q_stride, const void* k_cache, c
   P.n_splits = n_splits;
   P.total_rows = static_cast<int>(rows);
   P.sm_scale = sm_scale;
+  P.req_list = nullptr;
 
   hipStream_t s = static_cast<hipStream_t>(stream);
-  dim3 grid(batch * (wave_heads ? num_kv_heads / 4 : num_kv_heads), n_splits, m_groups);
+  const int hgroups = wave_heads ? num_kv_heads / 4 : num_kv_heads;
+  int rc;
   profile_begin(s);
-  if (mtq == 1 && wave_heads)
-    hipLaunchKernelGGL((verify_attn_kernel<1, true>), grid, dim3(256), 0, s, P);
-  else if (mtq == 1)
-    hipLaunchKernelGGL((verify_attn_kernel<1, false>), grid, dim3(256), 0, s, P);
-  else if (wave_heads)
-    hipLaunchKernelGGL((verify_attn_kernel<2, true>), grid, dim3(256), 0, s, P);
-  else
-    hipLaunchKernelGGL((verify_attn_kernel<2, false>), grid, dim3(256), 0, s, P);
+  if (!split_lists) {
+    // query lengths unknown on the host: rows per request in the common case decide the tile shape; long
+    // drafts of a mixed batch take extra row groups (re-reading their KV through L2)
+    const int avg_rows = (num_tokens + batch - 1) / batch * G;
+    const int mtq = (max_rows <= 16 || avg_rows <= 24) ? 1 : 2;
+    P.m_groups = (max_rows + mtq * 16 - 1) / (mtq * 16);
+    P.n_items = batch * hgroups;
+    dim3 grid(static_cast<unsigned>((P.n_items + 7) / 8 * 8 * P.m_groups), n_splits, 1);
+    if (mtq == 1 && wave_heads)
+      hipLaunchKernelGGL((verify_attn_kernel<1, true>), grid, dim3(256), 0, s, P);
+    else if (mtq == 1)
+      hipLaunchKernelGGL((verify_attn_kernel<1, false>), grid, dim3(256), 0, s, P);
+    else if (wave_heads)
+      hipLaunchKernelGGL((verify_attn_kernel<2, true>), grid, dim3(256), 0, s, P);
+    else
+      hipLaunchKernelGGL((verify_attn_kernel<2, false>), grid, dim3(256), 0, s, P);
+  } else {
+    // the caller partitioned the batch: `short_reqs` have q_len * G <= 16 rows (one MFMA tile, one pass),
+    // `long_reqs` go through the shared-tile kernel that reads their KV once for up to 192 rows
+    if (n_short > 0) {
+      P.req_list = short_reqs;
+      P.m_groups = 1;
+      P.n_items = n_short * hgroups;
+      dim3 grid(static_cast<unsigned>((P.n_items + 7) / 8 * 8), n_splits, 1);
+      if (wave_heads)
+        hipLaunchKernelGGL((verify_attn_kernel<1, true>), grid, dim3(256), 0, s, P);
+      else
+        hipLaunchKernelGGL((verify_attn_kernel<1, false>), grid, dim3(256), 0, s, P);
+    }
+    if (n_long > 0) {
+      P.req_list = long_reqs;
+      const int per_block_rows = 4 * kLongTilesPerWave * 16;
+      dim3 grid(static_cast<unsigned>(n_long * num_kv_heads), n_splits, (max_rows + per_block_rows - 1) / per_block_rows);
+      hipLaunchKernelGGL(verify_attn_long_kernel, grid, dim3(256), 0, s, P);
+    }
+  }
   profile_end(s);
-  int rc = launch_status("verify_attn_kernel");
-  if (rc != AIC_OK) return rc;
+  if ((rc = launch_status("verify_attn_kernel")) != AIC_OK) return rc;
   hipLaunchKernelGGL(verify_attn_combine_kernel, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s, P.ws_o,
                      P.ws_ml, n_splits, static_cast<int>(rows), num_q_heads, static_cast<uint16_t*>(out), out_stride);
   return launch_status("verify_attn_combine_kernel");
+}
+
+int aic_verify_attention(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
+                         int64_t block_stride, int kv_dtype, const float* k_scale, const float* v_scale,
+                         const int32_t* block_table, int max_blocks_per_seq, const int32_t* seq_lens,
+                         const int32_t* query_start_loc, int batch, int num_tokens, int max_q_len, int num_q_heads,
+                         int num_kv_heads, int head_size, int block_size, float sm_scale, void* out,
+                         int64_t out_stride, void* workspace, size_t workspace_bytes, int max_seq_len, void* stream) {
+  return aic_verify_attention_ex(q, q_stride, k_cache, v_cache, block_stride, kv_dtype, k_scale, v_scale, block_table,
+                                 max_blocks_per_seq, seq_lens, query_start_loc, batch, num_tokens, max_q_len,
+                                 num_q_heads, num_kv_heads, head_size, block_size, sm_scale, out, out_stride, workspace,
+                                 workspace_bytes, max_seq_len, nullptr, 0, nullptr, 0, stream);
 }
 
 }  // extern "C"

@@ -187,6 +187,7 @@ class HotPathEngine:
 
         # (a) KV of the step's tokens for every layer in one launch (A16), then (b) verify attention per layer
         self._write_kv(reqs, q_len, qsl, T)
+        self._req_split = ops.split_requests(q_len, self.hq_local // self.hkv_local, dev)
         self._attention_layers(T, bt, d_seq, d_qsl, max_q, max_ctx)
 
         # (c) verify logits: plant, accept, un-plant
@@ -300,6 +301,7 @@ class HotPathEngine:
             out = self.attn_out[:T].view(T, s.num_q_heads, s.head_size)
             for layer in range(s.num_layers):
                 kv = self.kv[layer]
-                ops.verify_attention(q, kv[0], kv[1], bt, d_seq, d_qsl, max_q, max_ctx, self.sm_scale, out=out)
+                ops.verify_attention(q, kv[0], kv[1], bt, d_seq, d_qsl, max_q, max_ctx, self.sm_scale, out=out,
+                                     req_split=self._req_split)
         else:
             self.ulysses.attention_layers(self, T, bt, d_seq, d_qsl, max_q, max_ctx)

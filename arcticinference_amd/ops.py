@@ -130,9 +130,11 @@ def rejection_sample(target_logits: torch.Tensor, draft_token_ids: torch.Tensor,
 # ------------------------------------------------------------------------------------------------
 def verify_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_table: torch.Tensor,
                      seq_lens: torch.Tensor, query_start_loc: torch.Tensor, max_q_len: int, max_seq_len: int,
-                     sm_scale: float, out: Optional[torch.Tensor] = None, num_splits_max: int = 64) -> torch.Tensor:
+                     sm_scale: float, out: Optional[torch.Tensor] = None, num_splits_max: int = 64,
+                     q_lens_host: Optional[Sequence[int]] = None, req_split=None) -> torch.Tensor:
     """q [T, Hq, D] (token stride may exceed Hq*D: a view into an all-to-all receive buffer works),
-    caches [num_blocks, block_size, Hkv, D]; returns [T, Hq, D]."""
+    caches [num_blocks, block_size, Hkv, D]; returns [T, Hq, D].  `q_lens_host` (the per-request query
+    lengths, which vLLM has on the host) lets long drafts take the shared-tile kernel."""
     _need_cuda(q, k_cache, v_cache, block_table, seq_lens, query_start_loc)
     T, Hq, D = q.shape
     nb, bs, Hkv, D2 = k_cache.shape
@@ -143,12 +145,31 @@ def verify_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     wsb = N.lib().aic_verify_attention_workspace_bytes(T, Hq, D, num_splits_max)
     ws = _workspace(wsb, q.device)
     kvd = N.torch_dtype_code(k_cache.dtype)
-    N.check(N.lib().aic_verify_attention(
+    if req_split is None and q_lens_host is not None:
+        req_split = split_requests(q_lens_host, Hq // Hkv, q.device)
+    short, n_short, long_, n_long = req_split if req_split is not None else (None, 0, None, 0)
+    N.check(N.lib().aic_verify_attention_ex(
         q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(), k_cache.stride(0), kvd, None, None,
         block_table.data_ptr(), block_table.size(1), seq_lens.data_ptr(), query_start_loc.data_ptr(), B, T,
         int(max_q_len), Hq, Hkv, D, bs, float(sm_scale), out.data_ptr(), out.stride(0), ws.data_ptr(), ws.numel(),
-        int(max_seq_len), N.current_stream_ptr()))
+        int(max_seq_len), _ptr(short) if n_short else None, n_short, _ptr(long_) if n_long else None, n_long,
+        N.current_stream_ptr()))
     return out
+
+
+def split_requests(q_lens_host: Sequence[int], group_size: int, device):
+    """Partition a batch by query length for aic_verify_attention_ex: (short_ids, n_short, long_ids, n_long) with
+    device int32 id lists, or None when every request fits one 16-row MFMA tile (q_len * Hq/Hkv <= 16).
+    Build it once per engine step and pass it to every layer's verify_attention call."""
+    import numpy as np
+    ql = np.asarray(q_lens_host)
+    is_short = ql * group_size <= 16
+    if is_short.all():
+        return None
+    order = np.concatenate([np.nonzero(is_short)[0], np.nonzero(~is_short)[0]]).astype(np.int32)
+    n_short = int(is_short.sum())
+    lists = torch.from_numpy(order).to(device, non_blocking=True)
+    return lists[:n_short], n_short, lists[n_short:], len(order) - n_short
 
 
 # ------------------------------------------------------------------------------------------------

@@ -257,6 +257,19 @@ int aic_verify_attention(const void* q, int64_t q_stride, const void* k_cache, c
                          int num_q_heads, int num_kv_heads, int head_size, int block_size, float sm_scale,
                          void* out, int64_t out_stride, void* workspace, size_t workspace_bytes,
                          int max_seq_len, void* stream);
+/* Same, for callers that know the query lengths on the host (vLLM keeps num_scheduled_tokens there):
+ * the batch is partitioned into `short_reqs` (device int32[n_short], requests with q_len * Hq/Hkv <= 16
+ * query rows: one MFMA tile, KV streamed once) and `long_reqs` (device int32[n_long], e.g. 33-token suffix
+ * drafts: a shared-tile kernel reads their KV once for up to 192 rows instead of once per 16-row group).
+ * max_q_len bounds the long requests.  Lists NULL/0 -> identical to aic_verify_attention. */
+int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
+                            int64_t block_stride, int kv_dtype, const float* k_scale, const float* v_scale,
+                            const int32_t* block_table, int max_blocks_per_seq, const int32_t* seq_lens,
+                            const int32_t* query_start_loc, int batch, int num_tokens, int max_q_len,
+                            int num_q_heads, int num_kv_heads, int head_size, int block_size, float sm_scale,
+                            void* out, int64_t out_stride, void* workspace, size_t workspace_bytes,
+                            int max_seq_len, const int32_t* short_reqs, int n_short, const int32_t* long_reqs,
+                            int n_long, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * A12  Ulysses head/sequence repartition — the copies around the two all-to-alls of

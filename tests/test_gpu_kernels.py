@@ -202,6 +202,8 @@ def _attn_case(B, Hq, Hkv, D, q_lens, ctxs, bs, seed):
     dict(B=2, Hq=32, Hkv=8, q_lens=[33, 9], ctxs=[700, 40], bs=16),        # suffix-length drafts, several row groups
     dict(B=2, Hq=16, Hkv=2, q_lens=[4, 4], ctxs=[515, 33], bs=32),         # G = 8, block_size 32
     dict(B=4, Hq=4, Hkv=1, q_lens=[4, 4, 4, 4], ctxs=[4100, 4099, 5, 4], bs=16),  # SP=8 slice of Llama-8B; ctx == q_len
+    dict(B=5, Hq=32, Hkv=8, q_lens=[4, 33, 2, 17, 4], ctxs=[900, 1300, 64, 2100, 33], bs=16),  # mixed LSTM / suffix drafts
+    dict(B=2, Hq=64, Hkv=8, q_lens=[33, 3], ctxs=[500, 70], bs=16),   # G = 8: 264 rows -> two 192-row groups
 ])
 def test_verify_attention(cfg):
     D = 128
@@ -211,6 +213,12 @@ def test_verify_attention(cfg):
     got = _ops().verify_attention(q.to(DEV), kc.to(DEV), vc.to(DEV), bt.to(DEV),
                                   torch.tensor(cfg["ctxs"], dtype=torch.int32, device=DEV),
                                   torch.tensor(qsl, device=DEV), max(cfg["q_lens"]), max(cfg["ctxs"]), scale)
+    # the same batch with host-known query lengths: long drafts go through the shared-tile kernel
+    got2 = _ops().verify_attention(q.to(DEV), kc.to(DEV), vc.to(DEV), bt.to(DEV),
+                                   torch.tensor(cfg["ctxs"], dtype=torch.int32, device=DEV),
+                                   torch.tensor(qsl, device=DEV), max(cfg["q_lens"]), max(cfg["ctxs"]), scale,
+                                   q_lens_host=cfg["q_lens"])
+    assert torch.allclose(got2.float().cpu(), want, atol=1e-3, rtol=2 ** -8), f"split path: {(got2.float().cpu() - want).abs().max()}"
     err = (got.float().cpu() - want).abs()
     # tolerance: BASELINE.json north_star asks for 1e-3 in bf16 -> atol 1e-3 plus one bf16 rounding of the
     # output itself (relative 2^-8); internally P.V runs at ~fp32 accuracy (bf16 hi+lo split)
