@@ -109,8 +109,10 @@ class HotPathEngine:
         self.requests: List[Optional[RequestState]] = [None] * max_num_seqs
         self.block_table = torch.zeros(max_num_seqs, self.blocks_per_seq, dtype=torch.int32, device=self.device)
         self.sm_scale = s.head_size ** -0.5
+        self._plant_col = torch.full((self.max_tokens, 1), 30.0, dtype=torch.bfloat16, device=self.device)
         self.stats = StepStats()
         self.last_suffix_stats: Dict = {}
+        self.timeline: Dict[str, float] = {}   # seconds accumulated per phase (host clock)
 
     # -- request management ---------------------------------------------------------------------------
     def add_request(self, slot: int, req_id, prompt: Sequence[int], first_token: int) -> None:
@@ -148,6 +150,12 @@ class HotPathEngine:
         """`next_truth(req, n)` -> the target model's greedy tokens for the next n positions of `req`
         (the synthetic target: its verify logits get these tokens planted as arg-max).
         Returns the tokens emitted per live request."""
+        import time as _t
+        _t0 = _t.perf_counter()
+        def _mark(name, _state=[_t0]):
+            now = _t.perf_counter()
+            self.timeline[name] = self.timeline.get(name, 0.0) + (now - _state[0])
+            _state[0] = now
         s, spec, dev = self.shape, self.spec, self.device
         live = [i for i, r in enumerate(self.requests) if r is not None]
         B = len(live)
@@ -187,26 +195,40 @@ class HotPathEngine:
 
         # (a) KV of the step's tokens for every layer in one launch (A16), then (b) verify attention per layer
         self._write_kv(reqs, q_len, qsl, T)
+        _mark('host_prepare')
         self._req_split = ops.split_requests(q_len, self.hq_local // self.hkv_local, dev)
         self._attention_layers(T, bt, d_seq, d_qsl, max_q, max_ctx)
 
+        _mark('enqueue_attention')
         # (c) verify logits: plant, accept, un-plant
         lg = self.logits[:T]
-        saved = lg[d_rows, d_plant].clone()
-        lg[d_rows, d_plant] = 30.0
+        col = d_plant.unsqueeze(1)
+        saved = torch.gather(lg, 1, col)
+        lg.scatter_(1, col, self._plant_col[:T])   # gather/scatter on device tensors only: nothing here may sync the stream
         bonus = torch.argmax(lg.index_select(0, d_brows), dim=-1).to(torch.int32)  # vLLM's sampler on the bonus rows
         tl = lg.index_select(0, d_trows) if len(target_rows) != T else lg
         max_spec = int(max(n_draft.max(), 1))
         rej = ops.rejection_sample(tl, d_draft, d_cu, bonus, max_spec)
-        lg[d_rows, d_plant] = saved
+        lg.scatter_(1, col, saved)
 
-        # (d) LSTM draft straight from the device-side acceptance results (no host round trip)
+        # (d) accepted tokens start their way to the host (pinned buffer, event) BEFORE the LSTM draft is
+        # enqueued: the draft needs nothing from the host (last token / hidden row come from the acceptance
+        # kernel on the device), so it runs while the host parses tokens and updates the suffix trees
+        if not hasattr(self, "_out_pin"):
+            self._out_pin = torch.empty(self.max_num_seqs * (MAX_SPEC_LEN + 2), dtype=torch.int32).pin_memory()
+            self._out_ev = torch.cuda.Event()
+        out_pin = self._out_pin[:B * (max_spec + 1)].view(B, max_spec + 1)   # contiguous: a strided pinned target makes the copy blocking
+        out_pin.copy_(rej.output_token_ids, non_blocking=True)
+        self._out_ev.record()
         lstm_out = None
         use_lstm = spec.method in ("arctic", "mlp_speculator") and self.drafter is not None and B <= spec.disable_by_batch_size
         if use_lstm:
             lstm_out = self.drafter.generate_proposals(rej.last_token, self.hidden, spec.num_speculative_tokens,
                                                        hidden_index=rej.hidden_index)
-        out_host = rej.output_token_ids.cpu().numpy()   # first (and only blocking) D2H of the step
+        _mark('enqueue_accept_and_draft')
+        self._out_ev.synchronize()                       # the step's only blocking wait before the proposals
+        out_host = out_pin.numpy()
+        _mark('wait_gpu_accept')
 
         # (e) host: parse, commit, update the suffix trees while the LSTM kernels run
         emitted: List[List[int]] = []
@@ -223,14 +245,18 @@ class HotPathEngine:
             r.drafts = []
         if B > spec.disable_by_batch_size:
             return emitted
+        _mark('host_parse')
         suffix_res: Optional[List[SuffixSpecResult]] = None
         if self.suffix_cache is not None:
             for r, toks in zip(reqs, emitted):
                 if toks:
                     self.suffix_cache.update_response(r.req_id, toks)          # _update_suffix_cache (:657-678)
+            _mark('host_suffix_update')
             suffix_res = self._propose_suffix(reqs, emitted)
+            _mark('suffix_speculate_roundtrip')
         # (f) merge (:555-566, :595-601)
         lstm_host = lstm_out.cpu().numpy() if lstm_out is not None else None
+        _mark('wait_lstm')
         min_score = 0 if spec.method == "suffix" else spec.num_speculative_tokens
         for i, r in enumerate(reqs):
             room = self.max_model_len - len(r.tokens) - 1
@@ -242,6 +268,7 @@ class HotPathEngine:
                 k = min(spec.num_speculative_tokens, room)
                 drafts = [int(t) for t in lstm_host[i, :max(k, 0)]]
             r.drafts = drafts[:max(room, 0)]
+        _mark('host_merge')
         return emitted
 
     # -- pieces -------------------------------------------------------------------------------------------

@@ -196,6 +196,7 @@ def main():
     N.lib().aic_profile_enable(1)
     gen_tokens[0] = 0
     eng.stats = type(eng.stats)()
+    eng.timeline = {}
     attn_bytes = [0.0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -255,6 +256,7 @@ def main():
             "draft_acceptance_rate": st.accepted / max(st.drafted, 1),
             "tokens_per_request_step": st.emitted / max(args.steps * B, 1),
             "suffix_share_of_drafts": st.suffix_used / max(args.steps * B, 1),
+            "host_timeline_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in eng.timeline.items()},
             "roofline": {"bound": "hbm", "kernel": "verify_attn_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_us": avg_launch_us, "launches": launches.value,
