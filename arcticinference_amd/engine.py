@@ -96,7 +96,7 @@ class HotPathEngine:
         self.kv = [torch.empty(2, nb, s.block_size, self.hkv_local, s.head_size, dtype=torch.bfloat16,
                                device=self.device).normal_(generator=g) for _ in range(s.num_layers)]
         self.max_tokens = max_num_seqs * (MAX_SPEC_LEN + 1)
-        tq = self.max_tokens
+        tq = self.max_tokens + 16   # + room for the SP padding of the token count
         # synthetic outputs of the target model's dense layers (real shapes)
         self.q_buf = torch.empty(tq, s.num_q_heads * s.head_size, dtype=torch.bfloat16, device=self.device).normal_(generator=g)
         self.k_buf = torch.empty(tq, s.num_kv_heads * s.head_size, dtype=torch.bfloat16, device=self.device).normal_(generator=g)
