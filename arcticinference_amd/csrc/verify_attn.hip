@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "aic_common.h"
 
@@ -495,12 +496,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
 
   if (t_begin < t_end) {
+    // tile t+1 sits in registers while tile t is computed and is written to the other LDS buffer at the TOP of
+    // the next iteration, so every global load has a whole iteration of MFMA work to land under
     AIC_LONG_LOAD(t_begin)
     AIC_LONG_STORE(0)
-    __syncthreads();
+    AIC_LONG_LOAD(t_begin + kTile)
     int buf = 0;
     for (int tt = t_begin; tt < t_end; tt += kTile, buf ^= 1) {
-      AIC_LONG_LOAD(tt + kTile)  // clamped into the context: always valid; unused past the range
+      __syncthreads();  // buffer `buf` is complete; every wave is done with buffer buf ^ 1
+      if (tt + kTile < t_end) AIC_LONG_STORE(buf ^ 1)
+      AIC_LONG_LOAD(tt + 2 * kTile)  // clamped into the context: always valid; unused past the range
       const char* kb = reinterpret_cast<const char*>(kv_lds[buf][0]);
       const char* vb = reinterpret_cast<const char*>(kv_lds[buf][1]);
       // K fragments of the tile (A operand of S^T = K Q^T): lane (token c16 [+16], d = 32 s + 8 g)
@@ -586,9 +591,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
           }
         }
       }
-      // next tile into the other buffer (its last readers finished before the previous barrier)
-      AIC_LONG_STORE(buf ^ 1)
-      __syncthreads();
     }
   }
 #undef AIC_LONG_LOAD
@@ -641,10 +643,32 @@ verify_attn_combine_kernel(const float* __restrict__ ws_o, const float* __restri
   *reinterpret_cast<uint32_t*>(op) = packed;
 }
 
+// Side stream for the long-draft kernel: a step's few long requests run beside the short-request kernel
+// instead of behind it (fork / join with two events; capturable in a hipGraph).
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  int device = -1;
+};
+static SideStream g_side;
+static int side_stream(SideStream** out) {
+  int dev = 0;
+  AIC_HIP_TRY(hipGetDevice(&dev));
+  if (g_side.stream == nullptr || g_side.device != dev) {
+    AIC_HIP_TRY(hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking));
+    AIC_HIP_TRY(hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming));
+    AIC_HIP_TRY(hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming));
+    g_side.device = dev;
+  }
+  *out = &g_side;
+  return AIC_OK;
+}
+
 static int pick_splits(int batch, int num_kv_heads, int m_groups, int max_seq_len, bool wave_heads) {
   // waves per split: one per kv head (wave_heads) or four per kv head (token range split over the waves)
   const int64_t base_waves = static_cast<int64_t>(batch) * num_kv_heads * m_groups * (wave_heads ? 1 : 4);
-  int64_t s = (6144 + base_waves - 1) / base_waves;  // ~3 waves per SIMD chip-wide
+  static const int64_t target = []() { const char* e = getenv("AIC_ATTN_WAVES"); return e ? atoll(e) : 4608LL; }();
+  int64_t s = (target + base_waves - 1) / base_waves;  // default: ~2 rounds of 3 waves per SIMD chip-wide
   const int max_tiles = (max_seq_len + kTile - 1) / kTile;
   const int64_t cap = std::max(1, wave_heads ? (max_tiles + 1) / 2 : (max_tiles + 7) / 8);  // >= ~2 tiles per wave
   if (s > cap) s = cap;
@@ -752,6 +776,21 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   } else {
     // the caller partitioned the batch: `short_reqs` have q_len * G <= 16 rows (one MFMA tile, one pass),
     // `long_reqs` go through the shared-tile kernel that reads their KV once for up to 192 rows
+    SideStream* side = nullptr;
+    const bool overlap = n_short > 0 && n_long > 0;
+    if (overlap) {
+      if ((rc = side_stream(&side)) != AIC_OK) return rc;
+      AIC_HIP_TRY(hipEventRecord(side->fork, s));
+      AIC_HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
+    }
+    if (n_long > 0) {
+      AttnParams PL = P;
+      PL.req_list = long_reqs;
+      const int per_block_rows = 4 * kLongTilesPerWave * 16;
+      dim3 grid(static_cast<unsigned>(n_long * num_kv_heads), n_splits, (max_rows + per_block_rows - 1) / per_block_rows);
+      hipLaunchKernelGGL(verify_attn_long_kernel, grid, dim3(256), 0, overlap ? side->stream : s, PL);
+      if (overlap) AIC_HIP_TRY(hipEventRecord(side->join, side->stream));
+    }
     if (n_short > 0) {
       P.req_list = short_reqs;
       P.m_groups = 1;
@@ -762,12 +801,7 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
       else
         hipLaunchKernelGGL((verify_attn_kernel<1, false>), grid, dim3(256), 0, s, P);
     }
-    if (n_long > 0) {
-      P.req_list = long_reqs;
-      const int per_block_rows = 4 * kLongTilesPerWave * 16;
-      dim3 grid(static_cast<unsigned>(n_long * num_kv_heads), n_splits, (max_rows + per_block_rows - 1) / per_block_rows);
-      hipLaunchKernelGGL(verify_attn_long_kernel, grid, dim3(256), 0, s, P);
-    }
+    if (overlap) AIC_HIP_TRY(hipStreamWaitEvent(s, side->join, 0));
   }
   profile_end(s);
   if ((rc = launch_status("verify_attn_kernel")) != AIC_OK) return rc;
