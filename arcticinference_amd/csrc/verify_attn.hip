@@ -77,6 +77,64 @@ __device__ __forceinline__ int v_tile_off(int t, int ch) {
 // eight workgroups at eight different times).  !WH (Hkv not a multiple of 4, e.g. one kv head per rank under
 // SP=8, where rows are contiguous anyway): the four waves split the token range of one head and are merged
 // through LDS at the end.
+// Online-softmax update of one 16-row query tile against one 32-token KV tile, in the S^T layout: the lane owns
+// query row c16 and the 8 tokens tt + 16 th + 4 g + e.  Scores are kept in the log2 domain (scale folded with
+// log2 e, v_exp_f32 is base 2).  Masking runs only on tiles that touch the causal edge or the end of the
+// range, and the O rescale only when some row's maximum moved: at 33-token drafts this VALU work, not HBM,
+// bounds the long-draft kernel.  Produces P as bf16 head + tail fragments (B operand of O^T = V^T P^T).
+__device__ __forceinline__ void softmax_tile(const f32x4& s0, const f32x4& s1, bool need_mask, bool row_ok, int tt,
+                                             int g, int t_end, int limit, float scale_log2, float& m_run,
+                                             float& l_run, f32x4 (&o)[8], bf16x8& pf, bf16x8& pl) {
+  float sc[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sc[e] = s0[e] * scale_log2;
+    sc[4 + e] = s1[e] * scale_log2;
+  }
+  if (need_mask) {
+#pragma unroll
+    for (int th = 0; th < 2; ++th)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int tok = tt + 16 * th + 4 * g + e;
+        if (!(row_ok && tok < t_end && tok <= limit)) sc[th * 4 + e] = -INFINITY;
+      }
+  }
+  float tmax = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
+  tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+  tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+  const float m_new = fmaxf(m_run, tmax);
+  float alpha = 1.0f, psum = 0.0f;
+  float pv[8];
+  if (m_new == -INFINITY) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pv[e] = 0.0f;
+  } else {
+    alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      pv[e] = __builtin_amdgcn_exp2f(sc[e] - m_new);
+      psum += pv[e];
+    }
+  }
+  psum += __shfl_xor(psum, 16);
+  psum += __shfl_xor(psum, 32);
+  l_run = l_run * alpha + psum;
+  m_run = m_new;
+  if (!__all(alpha == 1.0f)) {
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) o[dt] *= alpha;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    pf[e] = static_cast<__bf16>(pv[e]);
+    pl[e] = static_cast<__bf16>(pv[e] - static_cast<float>(pf[e]));
+  }
+}
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
 template <int MTQ, bool WH>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ == 1 ? 3 : 2, MTQ == 1 ? 3 : 2))) verify_attn_kernel(AttnParams P) {
   // per wave: one 32-token V tile (8 KiB); reused at the end for the cross-wave merge
@@ -118,6 +176,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ ==
   const int64_t kv_row = static_cast<int64_t>(Hkv) * kD;  // elements between consecutive tokens of a page
   const int32_t* btab = P.block_table + static_cast<int64_t>(req) * P.max_blocks;
   const int bs = P.block_size;  // multiple of 16: a 16-token group never straddles two pages
+  const float scale_log2 = P.sm_scale * kLog2e;
 
   // ---- query fragments (B operand of S^T = K Q^T): lane (row c16, k-group g) ----------------------
   uint4 qf[MTQ][4];
@@ -240,52 +299,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ ==
       pages_next = tile_pages(tn + kTile);
 
       bf16x8 pfrag[MTQ], pfrag_lo[MTQ];
+      const bool need_mask = tn > t_end || tn > ctx - q_len + 1;  // the tile reaches the causal edge / range end
 #pragma unroll
       for (int mt = 0; mt < MTQ; ++mt) {
-        // lane: query row c16, tokens tt + 16 th + 4 g + e
-        const int limit = ctx - q_len + row_pos[mt];
-        float sc[8];
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int th = 0; th < 2; ++th)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int tok = tt + 16 * th + 4 * g + e;
-            const bool vis = row_ok[mt] && tok < t_end && tok <= limit;
-            const float v = vis ? st[mt][th][e] * P.sm_scale : -INFINITY;
-            sc[th * 4 + e] = v;
-            tmax = fmaxf(tmax, v);
-          }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m_run[mt], tmax);
-        float alpha = 1.0f, psum = 0.0f;
-        float pv[8];
-        if (m_new == -INFINITY) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) pv[e] = 0.0f;
-        } else {
-          alpha = __expf(m_run[mt] - m_new);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            pv[e] = __expf(sc[e] - m_new);
-            psum += pv[e];
-          }
-        }
-        psum += __shfl_xor(psum, 16);
-        psum += __shfl_xor(psum, 32);
-        l_run[mt] = l_run[mt] * alpha + psum;
-        m_run[mt] = m_new;
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt) o_acc[mt][dt] *= alpha;
-        bf16x8 pf, pl;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          pf[e] = static_cast<__bf16>(pv[e]);
-          pl[e] = static_cast<__bf16>(pv[e] - static_cast<float>(pf[e]));
-        }
-        pfrag[mt] = pf;
-        pfrag_lo[mt] = pl;
+        softmax_tile(st[mt][0], st[mt][1], need_mask, row_ok[mt], tt, g, t_end, ctx - q_len + row_pos[mt], scale_log2,
+                     m_run[mt], l_run[mt], o_acc[mt], pfrag[mt], pfrag_lo[mt]);
       }
 
       // 5. O^T += V^T P^T : A = V^T fragment via transposing LDS reads
@@ -333,7 +351,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ ==
             make_float4(o_acc[mt][dt][0], o_acc[mt][dt][1], o_acc[mt][dt][2], o_acc[mt][dt][3]);
       if (g == 0) {
         float* mp = P.ws_ml + (static_cast<int64_t>(blockIdx.y) * P.total_rows + grow) * 2;
-        mp[0] = m_run[mt];
+        mp[0] = m_run[mt] * kLn2;  // the combine kernel works in natural-log units
         mp[1] = l_run[mt];
       }
     }
@@ -360,11 +378,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ ==
     float L = 0.0f;
     for (int w = 0; w < 4; ++w) {
       const float mw = xm[(w * MTQ + mt) * 16 + c16];
-      if (mw > -INFINITY) L += xl[(w * MTQ + mt) * 16 + c16] * __expf(mw - M);
+      if (mw > -INFINITY) L += xl[(w * MTQ + mt) * 16 + c16] * __builtin_amdgcn_exp2f(mw - M);
     }
     m_all[mt] = M;
     l_all[mt] = L;
-    scale_w[mt] = m_run[mt] > -INFINITY ? __expf(m_run[mt] - M) : 0.0f;
+    scale_w[mt] = m_run[mt] > -INFINITY ? __builtin_amdgcn_exp2f(m_run[mt] - M) : 0.0f;
   }
   if (wave > 0) {
 #pragma unroll
@@ -401,7 +419,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ ==
     }
     if (g == 0) {
       float* mp = P.ws_ml + (static_cast<int64_t>(bpart) * P.total_rows + grow) * 2;
-      mp[0] = m_all[mt];
+      mp[0] = m_all[mt] * kLn2;
       mp[1] = l_all[mt];
     }
   }
@@ -444,6 +462,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int32_t* btab = P.block_table + static_cast<int64_t>(req) * P.max_blocks;
   const int bs = P.block_size;
   const int last_group = (ctx - 1) & ~15;
+  const float scale_log2 = P.sm_scale * kLog2e;
 
   // query fragments of this wave's row tiles
   uint4 qf[RT][4];
@@ -516,6 +535,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int s = 0; s < 4; ++s) kf[th][s] = *reinterpret_cast<const uint4*>(kb + v_tile_off(16 * th + c16, 4 * s + g));
 
       bf16x8 pfrag[RT], pfrag_lo[RT];
+      const bool need_mask = tt + kTile > t_end || tt + kTile > ctx - q_len + 1;
 #pragma unroll
       for (int mt = 0; mt < RT; ++mt) {
         f32x4 st[2];
@@ -527,49 +547,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             st[th] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[th][s]),
                                                              __builtin_bit_cast(bf16x8, qf[mt][s]), st[th], 0, 0, 0);
         }
-        const int limit = ctx - q_len + row_pos[mt];
-        float sc[8];
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int th = 0; th < 2; ++th)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int tok = tt + 16 * th + 4 * g + e;
-            const bool vis = row_ok[mt] && tok < t_end && tok <= limit;
-            const float v = vis ? st[th][e] * P.sm_scale : -INFINITY;
-            sc[th * 4 + e] = v;
-            tmax = fmaxf(tmax, v);
-          }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m_run[mt], tmax);
-        float alpha = 1.0f, psum = 0.0f;
-        float pv[8];
-        if (m_new == -INFINITY) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) pv[e] = 0.0f;
-        } else {
-          alpha = __expf(m_run[mt] - m_new);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            pv[e] = __expf(sc[e] - m_new);
-            psum += pv[e];
-          }
-        }
-        psum += __shfl_xor(psum, 16);
-        psum += __shfl_xor(psum, 32);
-        l_run[mt] = l_run[mt] * alpha + psum;
-        m_run[mt] = m_new;
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt) o_acc[mt][dt] *= alpha;
-        bf16x8 pf, pl;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          pf[e] = static_cast<__bf16>(pv[e]);
-          pl[e] = static_cast<__bf16>(pv[e] - static_cast<float>(pf[e]));
-        }
-        pfrag[mt] = pf;
-        pfrag_lo[mt] = pl;
+        softmax_tile(st[0], st[1], need_mask, row_ok[mt], tt, g, t_end, ctx - q_len + row_pos[mt], scale_log2, m_run[mt],
+                     l_run[mt], o_acc[mt], pfrag[mt], pfrag_lo[mt]);
       }
       {
         const int q4 = c16 >> 2, p4 = c16 & 3;
@@ -609,7 +588,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
           make_float4(o_acc[mt][dt][0], o_acc[mt][dt][1], o_acc[mt][dt][2], o_acc[mt][dt][3]);
     if (g == 0) {
       float* mp = P.ws_ml + (static_cast<int64_t>(blockIdx.y) * P.total_rows + grow) * 2;
-      mp[0] = m_run[mt];
+      mp[0] = m_run[mt] * kLn2;
       mp[1] = l_run[mt];
     }
   }

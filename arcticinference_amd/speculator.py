@@ -188,25 +188,38 @@ class ArcticLSTMSpeculator:
             return out
         # vocab-parallel: local (value, index) per head, one all-gather of 2B int64, arg-max over ranks
         import torch.distributed as dist
-        N.check(N.lib().aic_lstm_begin(self._h, hs.data_ptr(), _p(hidx), B, stream))
+        self.begin(hs, hidx, B)
         outs = []
         last = toks
-        tok_l = torch.empty(B, dtype=torch.int64, device=self.device)
-        val_l = torch.empty(B, dtype=torch.float32, device=self.device)
         for head in range(k):
-            N.check(N.lib().aic_lstm_head(self._h, head, last.data_ptr(), B, tok_l.data_ptr(), val_l.data_ptr(),
-                                          N.current_stream_ptr()))
+            tok_l, val_l = self.head_step(head, last, B)
             packed = torch.cat([val_l.to(torch.float64).view(torch.int64), tok_l])
             gathered = torch.empty(self.tp_size * 2 * B, dtype=torch.int64, device=self.device)
             dist.all_gather_into_tensor(gathered, packed, group=self.tp_group)
-            g = gathered.view(self.tp_size, 2, B)
-            vals = g[:, 0, :].view(torch.float64)
-            idxs = g[:, 1, :]
-            win = torch.argmax(vals, dim=0, keepdim=True)  # first maximum = lowest rank = lowest index
-            nxt = torch.gather(idxs, 0, win).reshape(B)
+            nxt = self.pick_global(gathered.view(self.tp_size, 2, B))
             outs.append(nxt.unsqueeze(1))
             last = nxt.to(torch.int32)
         return torch.cat(outs, dim=-1)
+
+    # the three pieces of the vocab-parallel loop (arctic_speculator.py:733-744), separately callable
+    def begin(self, hidden: torch.Tensor, hidden_index: Optional[torch.Tensor], batch: int) -> None:
+        N.check(N.lib().aic_lstm_begin(self._h, hidden.data_ptr(), _p(hidden_index), batch, N.current_stream_ptr()))
+
+    def head_step(self, head: int, last_tokens: torch.Tensor, batch: int):
+        """One head on this rank's vocab shard: (global token id of the local arg-max, its bf16-rounded logit)."""
+        tok = torch.empty(batch, dtype=torch.int64, device=self.device)
+        val = torch.empty(batch, dtype=torch.float32, device=self.device)
+        N.check(N.lib().aic_lstm_head(self._h, head, last_tokens.data_ptr(), batch, tok.data_ptr(), val.data_ptr(),
+                                      N.current_stream_ptr()))
+        return tok, val
+
+    @staticmethod
+    def pick_global(gathered: torch.Tensor) -> torch.Tensor:
+        """gathered [tp, 2, B] int64 = per rank (f64 bits of the value, global index): first maximum over ranks,
+        i.e. lowest rank = lowest index on ties, like torch.argmax over the gathered values."""
+        vals = gathered[:, 0, :].contiguous().view(torch.float64)
+        win = torch.argmax(vals, dim=0, keepdim=True)
+        return torch.gather(gathered[:, 1, :], 0, win).reshape(-1)
 
     def _replay_graph(self, hs, toks, B, k):
         pad = padding_size(B)

@@ -1,0 +1,82 @@
+"""GPU: the whole hot loop (engine.HotPathEngine = the execute_model slice of SURVEY §3.3) against an
+oracle-driven replay of the same seeded workload: emitted tokens must be the ground-truth stream, and the
+drafts chosen each step must be what the reference policy (oracle SuffixCache + selection rule of
+model_runner.py:555-566, :595-601) would choose, with the LSTM tokens taken from the engine's own drafter."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.suffix_oracle import OracleSuffixCache
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(method, with_lstm):
+    from arcticinference_amd.engine import HotPathEngine, ModelShape, SpecConfig
+    from arcticinference_amd.speculator import ArcticLSTMSpeculator, LSTMSpeculatorConfig, random_lstm_weights
+    shape = ModelShape(num_layers=2, num_q_heads=8, num_kv_heads=4, head_size=128, hidden_size=512, vocab_size=2000,
+                       block_size=16)
+    spec = SpecConfig(method=method, num_speculative_tokens=3, enable_suffix_decoding=True)
+    drafter = None
+    if with_lstm:
+        cfg = LSTMSpeculatorConfig(vocab_size=2000, input_hidden_dim=512, inner_dim="512", emb_dim="512", proj_dim="512")
+        drafter = ArcticLSTMSpeculator(cfg, max_num_seqs=4, device="cuda", quantize_lm_head=False)
+        drafter.load_weights(random_lstm_weights(cfg, seed=0, std=0.05).items())
+    return HotPathEngine(shape, spec, 4, 400, drafter, device="cuda", seed=0), spec
+
+
+@pytest.mark.parametrize("method,with_lstm", [("suffix", False), ("arctic", True)])
+def test_engine_steps_match_oracle_policy(method, with_lstm):
+    from arcticinference_amd.workload import TokenSource
+    from arcticinference_amd.vllm_plugin.runner_logic import MAX_SPEC_LEN
+    eng, spec = _build(method, with_lstm)
+    src = TokenSource(vocab_size=2000, seed=3, n_motifs=3, motif_min=8, motif_max=16, p_motif=0.9)
+    B, PL = 4, 96
+    streams = {r: src.stream(PL + 200, r) for r in range(B)}
+    eng.add_requests(list(range(B)), list(range(B)), [streams[r][:PL] for r in range(B)],
+                     [int(streams[r][PL]) for r in range(B)])
+    orc = OracleSuffixCache(spec.suffix_cache_max_depth)
+    for r in range(B):
+        orc.cache_prompt(r, [int(x) for x in streams[r][:PL]])
+        orc.update_response(r, [int(streams[r][PL])])
+
+    def truth(req, n):
+        s = streams[req.req_id]
+        return s[len(req.tokens):len(req.tokens) + n]
+
+    min_score = 0 if method == "suffix" else spec.num_speculative_tokens
+    used_suffix = used_long = 0
+    for step in range(30):
+        before = [len(r.tokens) for r in eng.requests]
+        drafts_before = [list(r.drafts) for r in eng.requests]
+        emitted = eng.step(truth)
+        for i, r in enumerate(eng.requests):
+            s = streams[r.req_id]
+            toks = emitted[i]
+            # greedy target follows the stream: accepted drafts + one more token, all equal to the ground truth
+            assert toks == [int(x) for x in s[before[i]:before[i] + len(toks)]], (step, i)
+            want_acc = 0
+            for d in drafts_before[i]:
+                if int(s[before[i] + want_acc]) == d:
+                    want_acc += 1
+                else:
+                    break
+            assert len(toks) == want_acc + 1
+            orc.update_response(r.req_id, toks)
+        # the reference updates the cache for the whole batch first (_update_suffix_cache), then proposes
+        for i, r in enumerate(eng.requests):
+            row = r.tokens
+            want = orc.speculate(r.req_id, row[-64:], max_spec_tokens=min(MAX_SPEC_LEN, 64, 400 - len(row) - 1))
+            if want.score >= min_score and want.token_ids:
+                assert r.drafts == want.token_ids, (step, i)
+                used_suffix += 1
+                used_long += len(want.token_ids) > 3
+            elif with_lstm:
+                assert len(r.drafts) == 3          # LSTM drafts (values checked in test_gpu_kernels)
+            else:
+                assert r.drafts == []
+    assert used_suffix > 10 and used_long > 0, (used_suffix, used_long)
+    st = eng.stats
+    assert st.emitted == sum(len(r.tokens) - 97 for r in eng.requests)
+    assert st.accepted <= st.drafted and st.num_drafts > 0
+    assert eng.suffix_cache._global_tree().selfcheck() == 0

@@ -326,3 +326,40 @@ def test_rejection_no_drafts():
                                   torch.tensor([5, 6, 7, 8], dtype=torch.int32, device=DEV), 1)
     assert res.output_token_ids.cpu().tolist() == [[5, -1], [6, -1], [7, -1], [8, -1]]
     assert res.hidden_index.cpu().tolist() == [0, 1, 2, 3] and res.last_token.cpu().tolist() == [5, 6, 7, 8]
+
+
+def test_lstm_vocab_parallel_shards_agree_with_single_rank():
+    """A11: the LM head sharded over tp=2 / tp=4 ranks (vocab padded to 64, even split, zero-filled tail), each
+    shard's local (value, index) merged the way the all-gather + arg-max of arctic_speculator.py:733-744 does,
+    must give the single-rank tokens.  Both "ranks" run on this one GPU; the collective is emulated by a stack."""
+    from arcticinference_amd.speculator import ArcticLSTMSpeculator, LSTMSpeculatorConfig, random_lstm_weights
+    cfg = LSTMSpeculatorConfig(vocab_size=3001, input_hidden_dim=512, inner_dim="512", emb_dim="512", proj_dim="512")
+    ck = random_lstm_weights(cfg, seed=5, std=0.05)
+    B, k = 6, 3
+    g = torch.Generator().manual_seed(9)
+    hidden = torch.randn(B, 512, generator=g).to(torch.bfloat16).to(DEV)
+    ids = torch.randint(0, 3001, (B,), generator=g).to(DEV)
+    single = ArcticLSTMSpeculator(cfg, max_num_seqs=8, device=DEV, quantize_lm_head=False)
+    single.load_weights(ck.items())
+    want = single.generate_proposals(ids, hidden, k).cpu()
+    for tp in (2, 4):
+        ranks = []
+        for r in range(tp):
+            m = ArcticLSTMSpeculator(cfg, max_num_seqs=8, tp_size=tp, tp_rank=r, device=DEV, quantize_lm_head=False)
+            m.load_weights(ck.items())
+            ranks.append(m)
+        assert sum(m.shard_rows for m in ranks) == 3001 and ranks[0].shard_size * tp >= 3001
+        for m in ranks:
+            m.begin(hidden, None, B)
+        last = ids.to(torch.int32)
+        outs = []
+        for head in range(k):
+            parts = []
+            for m in ranks:
+                tok, val = m.head_step(head, last, B)
+                parts.append(torch.stack([val.to(torch.float64).view(torch.int64), tok]))
+            nxt = ArcticLSTMSpeculator.pick_global(torch.stack(parts))
+            outs.append(nxt.unsqueeze(1))
+            last = nxt.to(torch.int32)
+        got = torch.cat(outs, dim=-1).cpu()
+        assert torch.equal(got, want), (tp, got, want)
