@@ -59,6 +59,8 @@ struct AttnParams {
   int m_groups;    // row groups of MTQ*16 query rows (folded into blockIdx.x)
   int n_items;     // requests of this launch * head groups
   const int32_t* req_list;  // request ids of this launch (device) or nullptr = identity
+  const float* k_scale;     // fp8 KV cache: per-tensor dequantisation scales (device scalars)
+  const float* v_scale;
   float sm_scale;
 };
 
@@ -132,10 +134,32 @@ __device__ __forceinline__ void softmax_tile(const f32x4& s0, const f32x4& s1, b
   }
 }
 
+// 8 e4m3 bytes (two dwords) -> 8 bf16 (exact: every e4m3 value is a bf16 value)
+__device__ __forceinline__ bf16x8 fp8x8_to_bf16x8(uint32_t lo, uint32_t hi) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(static_cast<int>(lo), false);
+  const f32x2 b = __builtin_amdgcn_cvt_pk_f32_fp8(static_cast<int>(lo), true);
+  const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(static_cast<int>(hi), false);
+  const f32x2 d = __builtin_amdgcn_cvt_pk_f32_fp8(static_cast<int>(hi), true);
+  bf16x8 r;
+  r[0] = static_cast<__bf16>(a[0]);
+  r[1] = static_cast<__bf16>(a[1]);
+  r[2] = static_cast<__bf16>(b[0]);
+  r[3] = static_cast<__bf16>(b[1]);
+  r[4] = static_cast<__bf16>(c[0]);
+  r[5] = static_cast<__bf16>(c[1]);
+  r[6] = static_cast<__bf16>(d[0]);
+  r[7] = static_cast<__bf16>(d[1]);
+  return r;
+}
+
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
-template <int MTQ, bool WH>
+// KV8: the cache holds OCP e4m3 bytes (A16 writes them); tiles are dequantised to bf16 in registers (exact),
+// k_scale folds into the soft-max scale and v_scale into the output, so no per-element scaling is needed.
+// One 16-byte K load then covers the k-slots of TWO MFMA steps, and the Q fragments use the same slot map.
+template <int MTQ, bool WH, bool KV8>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ == 1 ? 3 : 2, MTQ == 1 ? 3 : 2))) verify_attn_kernel(AttnParams P) {
   // per wave: one 32-token V tile (8 KiB); reused at the end for the cross-wave merge
   constexpr int kMergeU4 = (8 * MTQ * 16 + 3 * MTQ * 16 * kD) / 4;
@@ -176,7 +200,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ ==
   const int64_t kv_row = static_cast<int64_t>(Hkv) * kD;  // elements between consecutive tokens of a page
   const int32_t* btab = P.block_table + static_cast<int64_t>(req) * P.max_blocks;
   const int bs = P.block_size;  // multiple of 16: a 16-token group never straddles two pages
-  const float scale_log2 = P.sm_scale * kLog2e;
+  const float scale_log2 = P.sm_scale * kLog2e * (KV8 ? *P.k_scale : 1.0f);
+  const float out_scale = KV8 ? *P.v_scale : 1.0f;
+  constexpr int ES = KV8 ? 1 : 2;  // bytes per cache element
+  const char* kc = reinterpret_cast<const char*>(P.k_cache);
+  const char* vc = reinterpret_cast<const char*>(P.v_cache);
 
   // ---- query fragments (B operand of S^T = K Q^T): lane (row c16, k-group g) ----------------------
   uint4 qf[MTQ][4];
@@ -189,9 +217,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ ==
     const int rc = min(rr, n_rows - 1);
     const int pos = rc / G, gq = rc - pos * G;
     row_pos[mt] = pos;
-    const uint16_t* qp = P.q + static_cast<int64_t>(q0 + pos) * P.q_stride + static_cast<int64_t>(h * G + gq) * kD + 8 * g;
+    const uint16_t* qrow = P.q + static_cast<int64_t>(q0 + pos) * P.q_stride + static_cast<int64_t>(h * G + gq) * kD;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[mt][s] = *reinterpret_cast<const uint4*>(qp + 32 * s);
+    for (int s = 0; s < 4; ++s)  // k-slot (s, g, j) -> d = 32 s + 8 g + j (bf16) | 64 (s/2) + 16 g + 8 (s%2) + j (fp8)
+      qf[mt][s] = *reinterpret_cast<const uint4*>(qrow + (KV8 ? 64 * (s >> 1) + 16 * g + 8 * (s & 1) : 32 * s + 8 * g));
   }
 
   float m_run[MTQ], l_run[MTQ];
@@ -229,36 +258,53 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ ==
   // scratch memory by the compiler whenever 3 waves per SIMD are requested.
   uint4 k00, k01, k02, k03, k10, k11, k12, k13;  // k<th><s>
   uint4 v0, v1, v2, v3, v4, v5, v6, v7;          // v<iv>
+  if (KV8) k02 = k03 = k12 = k13 = v4 = v5 = v6 = v7 = make_uint4(0, 0, 0, 0);
 #define AIC_LOAD_K(tt_, tp_)                                                                                   \
   {                                                                                                            \
     const int off0_ = min((tt_) + c16, ctx - 1) - (tp_).first0;                                                \
     const int off1_ = min((tt_) + 16 + c16, ctx - 1) - (tp_).first1;                                           \
-    const uint16_t* kp0_ = P.k_cache + (tp_).base0 + static_cast<int64_t>(off0_) * kv_row + 8 * g;             \
-    const uint16_t* kp1_ = P.k_cache + (tp_).base1 + static_cast<int64_t>(off1_) * kv_row + 8 * g;             \
+    const char* kp0_ = kc + ((tp_).base0 + static_cast<int64_t>(off0_) * kv_row) * ES + 16 * g;                \
+    const char* kp1_ = kc + ((tp_).base1 + static_cast<int64_t>(off1_) * kv_row) * ES + 16 * g;                \
     k00 = *reinterpret_cast<const uint4*>(kp0_);                                                               \
-    k01 = *reinterpret_cast<const uint4*>(kp0_ + 32);                                                          \
-    k02 = *reinterpret_cast<const uint4*>(kp0_ + 64);                                                          \
-    k03 = *reinterpret_cast<const uint4*>(kp0_ + 96);                                                          \
+    k01 = *reinterpret_cast<const uint4*>(kp0_ + 64);                                                          \
     k10 = *reinterpret_cast<const uint4*>(kp1_);                                                               \
-    k11 = *reinterpret_cast<const uint4*>(kp1_ + 32);                                                          \
-    k12 = *reinterpret_cast<const uint4*>(kp1_ + 64);                                                          \
-    k13 = *reinterpret_cast<const uint4*>(kp1_ + 96);                                                          \
+    k11 = *reinterpret_cast<const uint4*>(kp1_ + 64);                                                          \
+    if (!KV8) {                                                                                                \
+      k02 = *reinterpret_cast<const uint4*>(kp0_ + 128);                                                       \
+      k03 = *reinterpret_cast<const uint4*>(kp0_ + 192);                                                       \
+      k12 = *reinterpret_cast<const uint4*>(kp1_ + 128);                                                       \
+      k13 = *reinterpret_cast<const uint4*>(kp1_ + 192);                                                       \
+    }                                                                                                          \
   }
+  // bf16: instruction iv moves tokens 4 iv + g, 16-byte chunk c16;  fp8: tokens 8 iv + lane/8, chunk lane%8
 #define AIC_V_ADDR(tt_, tp_, iv_)                                                                              \
-  (P.v_cache + ((iv_) >= 4 ? (tp_).base1 : (tp_).base0) +                                                      \
-   static_cast<int64_t>(min((tt_) + 4 * (iv_) + g, ctx - 1) - ((iv_) >= 4 ? (tp_).first1 : (tp_).first0)) * kv_row + 8 * c16)
+  (KV8 ? vc + ((iv_) >= 2 ? (tp_).base1 : (tp_).base0) +                                                        \
+             static_cast<int64_t>(min((tt_) + 8 * (iv_) + (lane >> 3), ctx - 1) - ((iv_) >= 2 ? (tp_).first1 : (tp_).first0)) * kv_row + 16 * (lane & 7) \
+       : vc + (((iv_) >= 4 ? (tp_).base1 : (tp_).base0) +                                                       \
+               static_cast<int64_t>(min((tt_) + 4 * (iv_) + g, ctx - 1) - ((iv_) >= 4 ? (tp_).first1 : (tp_).first0)) * kv_row) * 2 + 16 * c16)
 #define AIC_LOAD_V(tt_, tp_)                                                                                   \
   {                                                                                                            \
     v0 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 0));                                             \
     v1 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 1));                                             \
     v2 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 2));                                             \
     v3 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 3));                                             \
-    v4 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 4));                                             \
-    v5 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 5));                                             \
-    v6 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 6));                                             \
-    v7 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 7));                                             \
+    if (!KV8) {                                                                                                \
+      v4 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 4));                                           \
+      v5 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 5));                                           \
+      v6 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 6));                                           \
+      v7 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 7));                                           \
+    }                                                                                                          \
   }
-#define AIC_STORE_V(iv_, reg_) *reinterpret_cast<uint4*>(vt + v_tile_off(4 * (iv_) + g, c16)) = reg_;
+#define AIC_STORE_V(iv_, reg_)                                                                                  \
+  if (KV8) {                                                                                                   \
+    if ((iv_) < 4) {                                                                                           \
+      const int tok_ = 8 * (iv_) + (lane >> 3), ch_ = 2 * (lane & 7);                                          \
+      *reinterpret_cast<bf16x8*>(vt + v_tile_off(tok_, ch_)) = fp8x8_to_bf16x8(reg_.x, reg_.y);                \
+      *reinterpret_cast<bf16x8*>(vt + v_tile_off(tok_, ch_ + 1)) = fp8x8_to_bf16x8(reg_.z, reg_.w);            \
+    }                                                                                                          \
+  } else {                                                                                                     \
+    *reinterpret_cast<uint4*>(vt + v_tile_off(4 * (iv_) + g, c16)) = reg_;                                     \
+  }
 
   // Software pipeline with ONE register set per operand: the registers of a tile are re-armed with the
   // next tile's loads as soon as their last consumer has issued (V: right after its LDS write, K: right
@@ -286,10 +332,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ ==
 #pragma unroll
       for (int mt = 0; mt < MTQ; ++mt) {
         f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = f32x4{0.f, 0.f, 0.f, 0.f};
-#define AIC_QK(acc_, kreg_, s_) \
-  acc_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kreg_), __builtin_bit_cast(bf16x8, qf[mt][s_]), acc_, 0, 0, 0);
-        AIC_QK(a0, k00, 0) AIC_QK(a0, k01, 1) AIC_QK(a0, k02, 2) AIC_QK(a0, k03, 3)
-        AIC_QK(a1, k10, 0) AIC_QK(a1, k11, 1) AIC_QK(a1, k12, 2) AIC_QK(a1, k13, 3)
+#define AIC_QK(acc_, kfrag_, s_) \
+  acc_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag_, __builtin_bit_cast(bf16x8, qf[mt][s_]), acc_, 0, 0, 0);
+#define AIC_B16(r_) __builtin_bit_cast(bf16x8, r_)
+        if (KV8) {
+          AIC_QK(a0, fp8x8_to_bf16x8(k00.x, k00.y), 0) AIC_QK(a0, fp8x8_to_bf16x8(k00.z, k00.w), 1)
+          AIC_QK(a0, fp8x8_to_bf16x8(k01.x, k01.y), 2) AIC_QK(a0, fp8x8_to_bf16x8(k01.z, k01.w), 3)
+          AIC_QK(a1, fp8x8_to_bf16x8(k10.x, k10.y), 0) AIC_QK(a1, fp8x8_to_bf16x8(k10.z, k10.w), 1)
+          AIC_QK(a1, fp8x8_to_bf16x8(k11.x, k11.y), 2) AIC_QK(a1, fp8x8_to_bf16x8(k11.z, k11.w), 3)
+        } else {
+          AIC_QK(a0, AIC_B16(k00), 0) AIC_QK(a0, AIC_B16(k01), 1) AIC_QK(a0, AIC_B16(k02), 2) AIC_QK(a0, AIC_B16(k03), 3)
+          AIC_QK(a1, AIC_B16(k10), 0) AIC_QK(a1, AIC_B16(k11), 1) AIC_QK(a1, AIC_B16(k12), 2) AIC_QK(a1, AIC_B16(k13), 3)
+        }
+#undef AIC_B16
 #undef AIC_QK
         st[mt][0] = a0;
         st[mt][1] = a1;
@@ -348,7 +403,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ ==
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt)
         *reinterpret_cast<float4*>(op + dt * 16) =
-            make_float4(o_acc[mt][dt][0], o_acc[mt][dt][1], o_acc[mt][dt][2], o_acc[mt][dt][3]);
+            make_float4(o_acc[mt][dt][0] * out_scale, o_acc[mt][dt][1] * out_scale, o_acc[mt][dt][2] * out_scale,
+                        o_acc[mt][dt][3] * out_scale);
       if (g == 0) {
         float* mp = P.ws_ml + (static_cast<int64_t>(blockIdx.y) * P.total_rows + grow) * 2;
         mp[0] = m_run[mt] * kLn2;  // the combine kernel works in natural-log units
@@ -382,7 +438,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ ==
     }
     m_all[mt] = M;
     l_all[mt] = L;
-    scale_w[mt] = m_run[mt] > -INFINITY ? __builtin_amdgcn_exp2f(m_run[mt] - M) : 0.0f;
+    scale_w[mt] = (m_run[mt] > -INFINITY ? __builtin_amdgcn_exp2f(m_run[mt] - M) : 0.0f) * out_scale;
   }
   if (wave > 0) {
 #pragma unroll
@@ -435,6 +491,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ ==
 // ------------------------------------------------------------------------------------------------------
 constexpr int kLongTilesPerWave = 3;
 
+template <bool KV8>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) verify_attn_long_kernel(AttnParams P) {
   constexpr int RT = kLongTilesPerWave;
   __shared__ uint4 kv_lds[2][2][kTile * 16];  // [buffer][K|V][32 tokens x 16 chunks]
@@ -462,7 +519,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int32_t* btab = P.block_table + static_cast<int64_t>(req) * P.max_blocks;
   const int bs = P.block_size;
   const int last_group = (ctx - 1) & ~15;
-  const float scale_log2 = P.sm_scale * kLog2e;
+  const float scale_log2 = P.sm_scale * kLog2e * (KV8 ? *P.k_scale : 1.0f);
+  const float out_scale = KV8 ? *P.v_scale : 1.0f;
+  const char* kc = reinterpret_cast<const char*>(P.k_cache);
+  const char* vc = reinterpret_cast<const char*>(P.v_cache);
 
   // query fragments of this wave's row tiles
   uint4 qf[RT][4];
@@ -489,29 +549,46 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int dt = 0; dt < 8; ++dt) o_acc[mt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  // cooperative tile load: thread t moves chunks t and t + 256 of K and of V (token = chunk / 16)
-  const int tk0 = threadIdx.x >> 4, tk1 = tk0 + 16, ch = threadIdx.x & 15;
+  // cooperative tile load.  bf16: thread t moves 16-byte chunks t and t + 256 of K and of V (token = chunk / 16);
+  // fp8: the tile is 256 chunks of 16 bytes, one per thread (token = t / 8), dequantised to bf16 at the LDS store
+  const int tk0 = KV8 ? threadIdx.x >> 3 : threadIdx.x >> 4, tk1 = tk0 + 16;
+  const int ch = KV8 ? threadIdx.x & 7 : threadIdx.x & 15;
   uint4 rk0, rk1, rv0, rv1;
+  if (KV8) rk1 = rv1 = make_uint4(0, 0, 0, 0);
 #define AIC_LONG_LOAD(tt_)                                                                                      \
   {                                                                                                             \
     const int f0_ = min((tt_), last_group), f1_ = min((tt_) + 16, last_group);                                  \
     const int64_t b0_ = static_cast<int64_t>(btab[f0_ / bs]) * P.block_stride + static_cast<int64_t>(f0_ % bs) * kv_row + h * kD; \
     const int64_t b1_ = static_cast<int64_t>(btab[f1_ / bs]) * P.block_stride + static_cast<int64_t>(f1_ % bs) * kv_row + h * kD; \
-    const int64_t o0_ = b0_ + static_cast<int64_t>(min((tt_) + tk0, ctx - 1) - f0_) * kv_row + 8 * ch;         \
-    const int64_t o1_ = b1_ + static_cast<int64_t>(min((tt_) + tk1, ctx - 1) - f1_) * kv_row + 8 * ch;         \
-    rk0 = *reinterpret_cast<const uint4*>(P.k_cache + o0_);                                                     \
-    rk1 = *reinterpret_cast<const uint4*>(P.k_cache + o1_);                                                     \
-    rv0 = *reinterpret_cast<const uint4*>(P.v_cache + o0_);                                                     \
-    rv1 = *reinterpret_cast<const uint4*>(P.v_cache + o1_);                                                     \
+    if (KV8) {                                                                                                  \
+      const bool hi_ = tk0 >= 16;                                                                               \
+      const int64_t o_ = (hi_ ? b1_ : b0_) + static_cast<int64_t>(min((tt_) + tk0, ctx - 1) - (hi_ ? f1_ : f0_)) * kv_row + 16 * ch; \
+      rk0 = *reinterpret_cast<const uint4*>(kc + o_);                                                           \
+      rv0 = *reinterpret_cast<const uint4*>(vc + o_);                                                           \
+    } else {                                                                                                    \
+      const int64_t o0_ = b0_ + static_cast<int64_t>(min((tt_) + tk0, ctx - 1) - f0_) * kv_row + 8 * ch;       \
+      const int64_t o1_ = b1_ + static_cast<int64_t>(min((tt_) + tk1, ctx - 1) - f1_) * kv_row + 8 * ch;       \
+      rk0 = *reinterpret_cast<const uint4*>(kc + 2 * o0_);                                                      \
+      rk1 = *reinterpret_cast<const uint4*>(kc + 2 * o1_);                                                      \
+      rv0 = *reinterpret_cast<const uint4*>(vc + 2 * o0_);                                                      \
+      rv1 = *reinterpret_cast<const uint4*>(vc + 2 * o1_);                                                      \
+    }                                                                                                           \
   }
 #define AIC_LONG_STORE(buf_)                                                                                    \
   {                                                                                                             \
     char* kb_ = reinterpret_cast<char*>(kv_lds[buf_][0]);                                                       \
     char* vb_ = reinterpret_cast<char*>(kv_lds[buf_][1]);                                                       \
-    *reinterpret_cast<uint4*>(kb_ + v_tile_off(tk0, ch)) = rk0;                                                 \
-    *reinterpret_cast<uint4*>(kb_ + v_tile_off(tk1, ch)) = rk1;                                                 \
-    *reinterpret_cast<uint4*>(vb_ + v_tile_off(tk0, ch)) = rv0;                                                 \
-    *reinterpret_cast<uint4*>(vb_ + v_tile_off(tk1, ch)) = rv1;                                                 \
+    if (KV8) {                                                                                                  \
+      *reinterpret_cast<bf16x8*>(kb_ + v_tile_off(tk0, 2 * ch)) = fp8x8_to_bf16x8(rk0.x, rk0.y);                \
+      *reinterpret_cast<bf16x8*>(kb_ + v_tile_off(tk0, 2 * ch + 1)) = fp8x8_to_bf16x8(rk0.z, rk0.w);            \
+      *reinterpret_cast<bf16x8*>(vb_ + v_tile_off(tk0, 2 * ch)) = fp8x8_to_bf16x8(rv0.x, rv0.y);                \
+      *reinterpret_cast<bf16x8*>(vb_ + v_tile_off(tk0, 2 * ch + 1)) = fp8x8_to_bf16x8(rv0.z, rv0.w);            \
+    } else {                                                                                                    \
+      *reinterpret_cast<uint4*>(kb_ + v_tile_off(tk0, ch)) = rk0;                                               \
+      *reinterpret_cast<uint4*>(kb_ + v_tile_off(tk1, ch)) = rk1;                                               \
+      *reinterpret_cast<uint4*>(vb_ + v_tile_off(tk0, ch)) = rv0;                                               \
+      *reinterpret_cast<uint4*>(vb_ + v_tile_off(tk1, ch)) = rv1;                                               \
+    }                                                                                                           \
   }
 
   if (t_begin < t_end) {
@@ -585,7 +662,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt)
       *reinterpret_cast<float4*>(op + dt * 16) =
-          make_float4(o_acc[mt][dt][0], o_acc[mt][dt][1], o_acc[mt][dt][2], o_acc[mt][dt][3]);
+          make_float4(o_acc[mt][dt][0] * out_scale, o_acc[mt][dt][1] * out_scale, o_acc[mt][dt][2] * out_scale,
+                      o_acc[mt][dt][3] * out_scale);
     if (g == 0) {
       float* mp = P.ws_ml + (static_cast<int64_t>(blockIdx.y) * P.total_rows + grow) * 2;
       mp[0] = m_run[mt] * kLn2;
@@ -686,17 +764,17 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   AIC_REQUIRE(!split_lists || (n_short >= 0 && n_long >= 0 && n_short + n_long == batch &&
                                (n_short == 0 || short_reqs) && (n_long == 0 || long_reqs)),
               "short/long request lists must partition the batch");
-  (void)k_scale;
-  (void)v_scale;
   if (head_size != kD) {
     set_error("head_size %d not supported yet (128 only)", head_size);
     return AIC_ERR_UNSUPPORTED;
   }
-  if (kv_dtype != AIC_DT_BF16) {
-    set_error("kv cache dtype %d not supported yet (bf16 only)", kv_dtype);
+  if (kv_dtype != AIC_DT_BF16 && kv_dtype != AIC_DT_FP8_E4M3) {
+    set_error("kv cache dtype %d not supported (bf16 or fp8 e4m3)", kv_dtype);
     return AIC_ERR_UNSUPPORTED;
   }
-  AIC_REQUIRE(q_stride % 8 == 0 && out_stride % 2 == 0 && block_stride % 8 == 0, "strides must keep 16-byte alignment");
+  const bool kv8 = kv_dtype == AIC_DT_FP8_E4M3;
+  AIC_REQUIRE(!kv8 || (k_scale && v_scale), "an fp8 kv cache needs k_scale and v_scale (device scalars)");
+  AIC_REQUIRE(q_stride % 8 == 0 && out_stride % 2 == 0 && block_stride % 16 == 0, "strides must keep 16-byte alignment");
   if (block_size % 16 != 0) {
     set_error("block_size %d not supported (must be a multiple of 16)", block_size);
     return AIC_ERR_UNSUPPORTED;
@@ -731,6 +809,8 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   P.total_rows = static_cast<int>(rows);
   P.sm_scale = sm_scale;
   P.req_list = nullptr;
+  P.k_scale = k_scale;
+  P.v_scale = v_scale;
 
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int hgroups = wave_heads ? num_kv_heads / 4 : num_kv_heads;
@@ -744,14 +824,20 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
     P.m_groups = (max_rows + mtq * 16 - 1) / (mtq * 16);
     P.n_items = batch * hgroups;
     dim3 grid(static_cast<unsigned>((P.n_items + 7) / 8 * 8 * P.m_groups), n_splits, 1);
-    if (mtq == 1 && wave_heads)
-      hipLaunchKernelGGL((verify_attn_kernel<1, true>), grid, dim3(256), 0, s, P);
-    else if (mtq == 1)
-      hipLaunchKernelGGL((verify_attn_kernel<1, false>), grid, dim3(256), 0, s, P);
-    else if (wave_heads)
-      hipLaunchKernelGGL((verify_attn_kernel<2, true>), grid, dim3(256), 0, s, P);
-    else
-      hipLaunchKernelGGL((verify_attn_kernel<2, false>), grid, dim3(256), 0, s, P);
+#define AIC_ATTN_LAUNCH(MTQ_, WH_)                                                                   \
+  if (kv8)                                                                                           \
+    hipLaunchKernelGGL((verify_attn_kernel<MTQ_, WH_, true>), grid, dim3(256), 0, s, P);             \
+  else                                                                                               \
+    hipLaunchKernelGGL((verify_attn_kernel<MTQ_, WH_, false>), grid, dim3(256), 0, s, P);
+    if (mtq == 1 && wave_heads) {
+      AIC_ATTN_LAUNCH(1, true)
+    } else if (mtq == 1) {
+      AIC_ATTN_LAUNCH(1, false)
+    } else if (wave_heads) {
+      AIC_ATTN_LAUNCH(2, true)
+    } else {
+      AIC_ATTN_LAUNCH(2, false)
+    }
   } else {
     // the caller partitioned the batch: `short_reqs` have q_len * G <= 16 rows (one MFMA tile, one pass),
     // `long_reqs` go through the shared-tile kernel that reads their KV once for up to 192 rows
@@ -767,7 +853,10 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
       PL.req_list = long_reqs;
       const int per_block_rows = 4 * kLongTilesPerWave * 16;
       dim3 grid(static_cast<unsigned>(n_long * num_kv_heads), n_splits, (max_rows + per_block_rows - 1) / per_block_rows);
-      hipLaunchKernelGGL(verify_attn_long_kernel, grid, dim3(256), 0, overlap ? side->stream : s, PL);
+      if (kv8)
+        hipLaunchKernelGGL(verify_attn_long_kernel<true>, grid, dim3(256), 0, overlap ? side->stream : s, PL);
+      else
+        hipLaunchKernelGGL(verify_attn_long_kernel<false>, grid, dim3(256), 0, overlap ? side->stream : s, PL);
       if (overlap) AIC_HIP_TRY(hipEventRecord(side->join, side->stream));
     }
     if (n_short > 0) {
@@ -775,13 +864,15 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
       P.m_groups = 1;
       P.n_items = n_short * hgroups;
       dim3 grid(static_cast<unsigned>((P.n_items + 7) / 8 * 8), n_splits, 1);
-      if (wave_heads)
-        hipLaunchKernelGGL((verify_attn_kernel<1, true>), grid, dim3(256), 0, s, P);
-      else
-        hipLaunchKernelGGL((verify_attn_kernel<1, false>), grid, dim3(256), 0, s, P);
+      if (wave_heads) {
+        AIC_ATTN_LAUNCH(1, true)
+      } else {
+        AIC_ATTN_LAUNCH(1, false)
+      }
     }
     if (overlap) AIC_HIP_TRY(hipStreamWaitEvent(s, side->join, 0));
   }
+#undef AIC_ATTN_LAUNCH
   profile_end(s);
   if ((rc = launch_status("verify_attn_kernel")) != AIC_OK) return rc;
   hipLaunchKernelGGL(verify_attn_combine_kernel, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s, P.ws_o,

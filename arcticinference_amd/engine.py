@@ -77,7 +77,8 @@ class HotPathEngine:
     slice (see arcticinference_amd/ulysses.py); everything else is replicated, as in the reference."""
 
     def __init__(self, shape: ModelShape, spec: SpecConfig, max_num_seqs: int, max_model_len: int,
-                 speculator: Optional[ArcticLSTMSpeculator], device: str = "cuda", ulysses=None, seed: int = 0):
+                 speculator: Optional[ArcticLSTMSpeculator], device: str = "cuda", ulysses=None, seed: int = 0,
+                 kv_cache_dtype: str = "auto"):
         self.shape, self.spec = shape, spec
         self.device = torch.device(device)
         self.max_num_seqs, self.max_model_len = max_num_seqs, max_model_len
@@ -93,8 +94,20 @@ class HotPathEngine:
         nb = max_num_seqs * self.blocks_per_seq
         g = torch.Generator(device=self.device).manual_seed(seed)
         # per-layer paged KV caches [2, num_blocks, block_size, Hkv_local, D] (llama_swiftkv.py:617 layout)
-        self.kv = [torch.empty(2, nb, s.block_size, self.hkv_local, s.head_size, dtype=torch.bfloat16,
-                               device=self.device).normal_(generator=g) for _ in range(s.num_layers)]
+        self.kv_cache_dtype = kv_cache_dtype
+        self.kv_scale = None
+        if kv_cache_dtype == "auto":
+            self.kv = [torch.empty(2, nb, s.block_size, self.hkv_local, s.head_size, dtype=torch.bfloat16,
+                                   device=self.device).normal_(generator=g) for _ in range(s.num_layers)]
+        else:   # OCP e4m3 cache (A16's fp8 path): random bytes re-interpreted, NaN codes cleared
+            assert kv_cache_dtype in ("fp8", "fp8_e4m3")
+            self.kv = []
+            for _ in range(s.num_layers):
+                raw = torch.randint(0, 256, (2, nb, s.block_size, self.hkv_local, s.head_size), dtype=torch.uint8,
+                                    device=self.device, generator=g)
+                raw[(raw & 0x7f) == 0x7f] = 0x30
+                self.kv.append(raw.view(torch.float8_e4m3fn))
+            self.kv_scale = torch.full((1,), 0.02, dtype=torch.float32, device=self.device)
         self.max_tokens = max_num_seqs * (MAX_SPEC_LEN + 1)
         tq = self.max_tokens + 16   # + room for the SP padding of the token count
         # synthetic outputs of the target model's dense layers (real shapes)
@@ -318,8 +331,9 @@ class HotPathEngine:
             self._one = [torch.ones(1, device=self.device) for _ in range(s.num_layers)]
             self._kc = [kv[0] for kv in self.kv]
             self._vc = [kv[1] for kv in self.kv]
-        ops.reshape_and_cache_flash_bulk(self._kv_new[0, :T], self._kv_new[1, :T], self._kc, self._vc, d_slots, "auto",
-                                         self._one, self._one, self.hkv_local, s.head_size)
+        scales = self._one if self.kv_scale is None else [self.kv_scale] * s.num_layers
+        ops.reshape_and_cache_flash_bulk(self._kv_new[0, :T], self._kv_new[1, :T], self._kc, self._vc, d_slots,
+                                         self.kv_cache_dtype, scales, scales, self.hkv_local, s.head_size)
 
     def _attention_layers(self, T, bt, d_seq, d_qsl, max_q, max_ctx) -> None:
         s = self.shape
@@ -329,6 +343,6 @@ class HotPathEngine:
             for layer in range(s.num_layers):
                 kv = self.kv[layer]
                 ops.verify_attention(q, kv[0], kv[1], bt, d_seq, d_qsl, max_q, max_ctx, self.sm_scale, out=out,
-                                     req_split=self._req_split)
+                                     req_split=self._req_split, k_scale=self.kv_scale, v_scale=self.kv_scale)
         else:
             self.ulysses.attention_layers(self, T, bt, d_seq, d_qsl, max_q, max_ctx)

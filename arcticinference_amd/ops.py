@@ -131,9 +131,11 @@ def rejection_sample(target_logits: torch.Tensor, draft_token_ids: torch.Tensor,
 def verify_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_table: torch.Tensor,
                      seq_lens: torch.Tensor, query_start_loc: torch.Tensor, max_q_len: int, max_seq_len: int,
                      sm_scale: float, out: Optional[torch.Tensor] = None, num_splits_max: int = 64,
-                     q_lens_host: Optional[Sequence[int]] = None, req_split=None) -> torch.Tensor:
+                     q_lens_host: Optional[Sequence[int]] = None, req_split=None,
+                     k_scale: Optional[torch.Tensor] = None, v_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q [T, Hq, D] (token stride may exceed Hq*D: a view into an all-to-all receive buffer works),
-    caches [num_blocks, block_size, Hkv, D]; returns [T, Hq, D].  `q_lens_host` (the per-request query
+    caches [num_blocks, block_size, Hkv, D] in bf16, or float8_e4m3fn with per-tensor `k_scale` / `v_scale`
+    (device scalars, the scales A16 divided by); returns [T, Hq, D].  `q_lens_host` (the per-request query
     lengths, which vLLM has on the host) lets long drafts take the shared-tile kernel."""
     _need_cuda(q, k_cache, v_cache, block_table, seq_lens, query_start_loc)
     T, Hq, D = q.shape
@@ -149,8 +151,8 @@ def verify_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
         req_split = split_requests(q_lens_host, Hq // Hkv, q.device)
     short, n_short, long_, n_long = req_split if req_split is not None else (None, 0, None, 0)
     N.check(N.lib().aic_verify_attention_ex(
-        q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(), k_cache.stride(0), kvd, None, None,
-        block_table.data_ptr(), block_table.size(1), seq_lens.data_ptr(), query_start_loc.data_ptr(), B, T,
+        q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(), k_cache.stride(0), kvd, _ptr(k_scale),
+        _ptr(v_scale), block_table.data_ptr(), block_table.size(1), seq_lens.data_ptr(), query_start_loc.data_ptr(), B, T,
         int(max_q_len), Hq, Hkv, D, bs, float(sm_scale), out.data_ptr(), out.stride(0), ws.data_ptr(), ws.numel(),
         int(max_seq_len), _ptr(short) if n_short else None, n_short, _ptr(long_) if n_long else None, n_long,
         N.current_stream_ptr()))

@@ -202,7 +202,7 @@ class UlyssesContext:
             out = eng.attn_out[:Tp].view(Tp, hq, D)
             qv = q_.unflatten(1, (hq, D))   # strided view into the all-to-all receive buffer
             ops.verify_attention(qv[:T], kv[0], kv[1], bt, d_seq, d_qsl, max_q, max_ctx, eng.sm_scale, out=out[:T],
-                                 req_split=eng._req_split)
+                                 req_split=eng._req_split, k_scale=eng.kv_scale, v_scale=eng.kv_scale)
             return eng.attn_out[:Tp]
 
         for layer in range(s.num_layers):

@@ -44,6 +44,7 @@ def parse_args():
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lstm", action="store_true")
+    ap.add_argument("--kv-dtype", default="auto", choices=["auto", "fp8"], help="KV cache dtype (auto = bf16, the headline config)")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
@@ -149,7 +150,8 @@ def main():
                                        quantize_lm_head=True)
         drafter.load_weights(random_lstm_weights(cfg, seed=args.seed).items())
 
-    eng = HotPathEngine(shape, spec, B, max_model_len, drafter, device=dev, ulysses=ulysses, seed=args.seed)
+    eng = HotPathEngine(shape, spec, B, max_model_len, drafter, device=dev, ulysses=ulysses, seed=args.seed,
+                        kv_cache_dtype=args.kv_dtype)
 
     # ---- workload: B live requests; finished ones are replaced by fresh ones ---------------------------
     streams = {}
@@ -202,7 +204,7 @@ def main():
     for _ in range(args.steps):
         # algorithmic KV bytes of one attention launch = sum_i ctx_i * 2 (K,V) * Hkv_local * D * 2 B
         ctx_sum = sum(len(r.tokens) + len(r.drafts) for r in eng.requests if r is not None)
-        attn_bytes[0] += ctx_sum * 2 * eng.hkv_local * shape.head_size * 2 * shape.num_layers
+        attn_bytes[0] += ctx_sum * 2 * eng.hkv_local * shape.head_size * (2 if args.kv_dtype == "auto" else 1) * shape.num_layers
         run_step()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -245,7 +247,7 @@ def main():
             "config": {
                 "workload": "Llama-3.1-8B shapes (L=%d, Hq=32, Hkv=8, D=128, V=128256), arctic LSTM speculator k=3 "
                             "(Ds=4096, fp8 head when padded batch <= 32) + suffix decoding, B=%d live requests, "
-                            "%d-token prompts, %d generated tokens each, greedy; hot path only (verify attention, "
+                            "%d-token prompts, %d generated tokens each, greedy, KV cache " + ("bf16" if args.kv_dtype == "auto" else "fp8 e4m3") + "; hot path only (verify attention, "
                             "acceptance, suffix + LSTM proposal, KV write); target dense layers synthetic" % (
                                 shape.num_layers, B, PL, GL),
                 "global_batch": B, "prompt_len": PL, "gen_len": GL,

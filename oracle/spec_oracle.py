@@ -186,7 +186,8 @@ def rejection_random(target_logits: torch.Tensor, draft_token_ids: Sequence[int]
 # verify attention — fp32 reference
 # ----------------------------------------------------------------------------------------------
 def verify_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_table: torch.Tensor,
-                     seq_lens: Sequence[int], query_start_loc: Sequence[int], sm_scale: float) -> torch.Tensor:
+                     seq_lens: Sequence[int], query_start_loc: Sequence[int], sm_scale: float, k_scale: float = 1.0,
+                     v_scale: float = 1.0) -> torch.Tensor:
     """q [T,Hq,D]; caches [num_blocks, block_size, Hkv, D]; returns fp32 [T,Hq,D]."""
     T, Hq, D = q.shape
     _, bs, Hkv, _ = k_cache.shape
@@ -199,8 +200,8 @@ def verify_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
             continue
         nblk = (ctx + bs - 1) // bs
         blocks = block_table[i, :nblk].long()
-        K = k_cache[blocks].reshape(-1, Hkv, D)[:ctx].float()  # [ctx, Hkv, D]
-        V = v_cache[blocks].reshape(-1, Hkv, D)[:ctx].float()
+        K = k_cache[blocks].reshape(-1, Hkv, D)[:ctx].float() * k_scale  # [ctx, Hkv, D]; fp8 caches hold x / scale
+        V = v_cache[blocks].reshape(-1, Hkv, D)[:ctx].float() * v_scale
         Q = q[q0:q1].float()                                     # [qlen, Hq, D]
         Kh = K.repeat_interleave(G, dim=1)                       # [ctx, Hq, D]
         Vh = V.repeat_interleave(G, dim=1)

@@ -225,6 +225,28 @@ def test_verify_attention(cfg):
     assert torch.allclose(got.float().cpu(), want, atol=1e-3, rtol=2 ** -8), f"max abs err {err.max()}"
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(B=3, Hq=32, Hkv=8, q_lens=[4, 1, 3], ctxs=[300, 17, 1025], bs=16),
+    dict(B=4, Hq=4, Hkv=1, q_lens=[4, 4, 2, 4], ctxs=[4100, 99, 5, 4], bs=16),           # token-split variant
+    dict(B=4, Hq=32, Hkv=8, q_lens=[4, 33, 2, 9], ctxs=[900, 1300, 64, 700], bs=32),   # long drafts, both paths
+])
+def test_verify_attention_fp8_kv(cfg):
+    """fp8 (e4m3) KV cache as written by the bulk KV op: K = k8 * k_scale, V = v8 * v_scale."""
+    D = 128
+    q, kc, vc, bt, qsl = _attn_case(cfg["B"], cfg["Hq"], cfg["Hkv"], D, cfg["q_lens"], cfg["ctxs"], cfg["bs"], seed=21)
+    ks, vs = 0.043, 0.021
+    k8 = O.fp8_sat(kc.float() / ks, "e4m3")
+    v8 = O.fp8_sat(vc.float() / vs, "e4m3")
+    scale = 1.0 / D ** 0.5
+    want = O.verify_attention(q, k8, v8, bt, cfg["ctxs"], qsl, scale, ks, vs)
+    args = (q.to(DEV), k8.to(DEV), v8.to(DEV), bt.to(DEV), torch.tensor(cfg["ctxs"], dtype=torch.int32, device=DEV),
+            torch.tensor(qsl, device=DEV), max(cfg["q_lens"]), max(cfg["ctxs"]), scale)
+    kw = dict(k_scale=torch.tensor([ks], device=DEV), v_scale=torch.tensor([vs], device=DEV))
+    for extra in ({}, {"q_lens_host": cfg["q_lens"]}):
+        got = _ops().verify_attention(*args, **kw, **extra)
+        assert torch.allclose(got.float().cpu(), want, atol=1e-3, rtol=2 ** -8), (extra, (got.float().cpu() - want).abs().max())
+
+
 def test_verify_attention_strided_q_and_peaked_softmax():
     """q as a column slice of an all-to-all receive buffer; one key dominates (forces the online-softmax rescale)."""
     D, Hq, Hkv = 128, 8, 2
