@@ -245,11 +245,11 @@ def main():
             "dtype": "bf16",
             "data": "synthetic",
             "config": {
-                "workload": "Llama-3.1-8B shapes (L=%d, Hq=32, Hkv=8, D=128, V=128256), arctic LSTM speculator k=3 "
-                            "(Ds=4096, fp8 head when padded batch <= 32) + suffix decoding, B=%d live requests, "
-                            "%d-token prompts, %d generated tokens each, greedy, KV cache " + ("bf16" if args.kv_dtype == "auto" else "fp8 e4m3") + "; hot path only (verify attention, "
-                            "acceptance, suffix + LSTM proposal, KV write); target dense layers synthetic" % (
-                                shape.num_layers, B, PL, GL),
+                "workload": ("Llama-3.1-8B shapes (L=%d, Hq=32, Hkv=8, D=128, V=128256), arctic LSTM speculator k=3 "
+                             "(Ds=4096, fp8 head when padded batch <= 32) + suffix decoding, B=%d live requests, "
+                             "%d-token prompts, %d generated tokens each, greedy, KV cache %s; hot path only (verify "
+                             "attention, acceptance, suffix + LSTM proposal, KV write); target dense layers synthetic"
+                             % (shape.num_layers, B, PL, GL, "bf16" if args.kv_dtype == "auto" else "fp8 e4m3")),
                 "global_batch": B, "prompt_len": PL, "gen_len": GL,
                 "parallelism": "sp%d" % world if world > 1 else "tp1",
             },
