@@ -194,20 +194,32 @@ class HotPathEngine:
         target_rows = np.nonzero(~is_bonus)[0]
         bonus_rows = qsl[1:] - 1
 
-        h2d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt, non_blocking=True)
-        d_seq = h2d(ctx, torch.int32)
-        d_qsl = h2d(qsl, torch.int32)
-        d_rows = h2d(np.arange(T), torch.int64)
-        d_plant = h2d(plant_tok, torch.int64)
-        d_draft = h2d(draft_flat, torch.int32)
-        d_cu = h2d(np.cumsum(n_draft), torch.int32)
-        d_trows = h2d(target_rows, torch.int64)
-        d_brows = h2d(bonus_rows, torch.int64)
-        slots = torch.tensor(live, dtype=torch.int64, device=dev)
+        # one pinned staging buffer and ONE host->device copy for all of the step's small index arrays
+        slot_map = self._slot_mapping(reqs, q_len, qsl, T)
+        parts = [ctx, qsl, draft_flat, np.cumsum(n_draft), plant_tok, target_rows, bonus_rows, np.asarray(live), slot_map]
+        kinds = [np.int32, np.int32, np.int32, np.int32, np.int64, np.int64, np.int64, np.int64, np.int64]
+        offs, nbytes = [], 0
+        for a, k in zip(parts, kinds):
+            nbytes = (nbytes + 15) & ~15
+            offs.append(nbytes)
+            nbytes += len(a) * np.dtype(k).itemsize
+        if not hasattr(self, "_stage_pin") or self._stage_pin.numel() < nbytes:
+            self._stage_pin = torch.empty(max(nbytes * 2, 1 << 16), dtype=torch.uint8).pin_memory()
+            self._stage_dev = torch.empty(self._stage_pin.numel(), dtype=torch.uint8, device=dev)
+        host = self._stage_pin.numpy()
+        for a, k, o in zip(parts, kinds, offs):
+            host[o:o + len(a) * np.dtype(k).itemsize].view(k)[:] = a
+        self._stage_dev[:nbytes].copy_(self._stage_pin[:nbytes], non_blocking=True)
+
+        def dview(i, tdt):
+            k = np.dtype(kinds[i]).itemsize
+            return self._stage_dev[offs[i]:offs[i] + len(parts[i]) * k].view(tdt)
+        d_seq, d_qsl, d_draft, d_cu = (dview(i, torch.int32) for i in range(4))
+        d_plant, d_trows, d_brows, slots, d_slots = (dview(i, torch.int64) for i in range(4, 9))
         bt = self.block_table.index_select(0, slots) if B != self.max_num_seqs else self.block_table
 
         # (a) KV of the step's tokens for every layer in one launch (A16), then (b) verify attention per layer
-        self._write_kv(reqs, q_len, qsl, T)
+        self._write_kv(d_slots, T)
         _mark('host_prepare')
         self._req_split = ops.split_requests(q_len, self.hq_local // self.hkv_local, dev)
         self._attention_layers(T, bt, d_seq, d_qsl, max_q, max_ctx)
@@ -314,14 +326,17 @@ class HotPathEngine:
             self.last_suffix_stats = self.suffix_cache.last_stats()
         return out
 
-    def _write_kv(self, reqs, q_len, qsl, T) -> None:
+    def _slot_mapping(self, reqs, q_len, qsl, T) -> np.ndarray:
         s = self.shape
         slot_map = np.empty(T, dtype=np.int64)
         for i, r in enumerate(reqs):
             first = len(r.tokens) - 1            # position of the last sampled token (not in the cache yet)
             pos = first + np.arange(q_len[i])
             slot_map[qsl[i]:qsl[i + 1]] = r.blocks[pos // s.block_size].astype(np.int64) * s.block_size + pos % s.block_size
-        d_slots = torch.from_numpy(slot_map).to(self.device, non_blocking=True)
+        return slot_map
+
+    def _write_kv(self, d_slots, T) -> None:
+        s = self.shape
         # synthetic K/V of the new tokens: one [T, L * Hkv_local * D] activation like SwiftKV's fused projection
         n = self.hkv_local * s.head_size
         if not hasattr(self, "_kv_new"):
