@@ -54,7 +54,8 @@ struct AttnParams {
   int num_q_heads;
   int num_kv_heads;
   int block_size;
-  int n_splits;
+  int n_splits;       // token-range splits of THIS launch
+  int n_parts_total;  // partial slots per row the combine kernel reads (max over the launches of a call)
   int total_rows;  // T * Hq
   int m_groups;    // row groups of MTQ*16 query rows (folded into blockIdx.x)
   int n_items;     // requests of this launch * head groups
@@ -153,17 +154,27 @@ __device__ __forceinline__ bf16x8 fp8x8_to_bf16x8(uint32_t lo, uint32_t hi) {
   return r;
 }
 
+// Rows written by a launch with fewer splits than the call's slot count mark their unused slots empty, so the
+// combine kernel can read a fixed number of slots per row (8 bytes per skipped slot).
+__device__ __forceinline__ void mark_unused_parts(const AttnParams& P, int64_t grow) {
+  for (int p = P.n_splits; p < P.n_parts_total; ++p) {
+    float* mp = P.ws_ml + (static_cast<int64_t>(p) * P.total_rows + grow) * 2;
+    mp[0] = -INFINITY;
+    mp[1] = 0.0f;
+  }
+}
+
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
 // KV8: the cache holds OCP e4m3 bytes (A16 writes them); tiles are dequantised to bf16 in registers (exact),
 // k_scale folds into the soft-max scale and v_scale into the output, so no per-element scaling is needed.
 // One 16-byte K load then covers the k-slots of TWO MFMA steps, and the Q fragments use the same slot map.
-template <int MTQ, bool WH, bool KV8>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ == 1 ? 3 : 2, MTQ == 1 ? 3 : 2))) verify_attn_kernel(AttnParams P) {
+template <int MTQ, bool WH, bool KV8, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((MTQ == 1 && NW == 4) ? 3 : 2, (MTQ == 1 && NW == 4) ? 3 : 2))) verify_attn_kernel(AttnParams P) {
   // per wave: one 32-token V tile (8 KiB); reused at the end for the cross-wave merge
   constexpr int kMergeU4 = (8 * MTQ * 16 + 3 * MTQ * 16 * kD) / 4;
-  constexpr int kLdsU4 = 4 * kTile * 16 > kMergeU4 ? 4 * kTile * 16 : kMergeU4;
+  constexpr int kLdsU4 = NW * kTile * 16 > kMergeU4 ? NW * kTile * 16 : kMergeU4;
   __shared__ uint4 v_lds_raw[kLdsU4];
   uint4(*v_lds)[kTile * 16] = reinterpret_cast<uint4(*)[kTile * 16]>(v_lds_raw);
 
@@ -171,7 +182,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ ==
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps loop control scalar
   const int g = lane >> 4, c16 = lane & 15;
   const int Hkv = P.num_kv_heads, Hq = P.num_q_heads, G = Hq / Hkv;
-  const int hgroups = WH ? Hkv / 4 : Hkv;
+  const int hgroups = WH ? Hkv / NW : Hkv;
   // blockIdx.x = ((item / 8) * m_groups + row_group) * 8 + item % 8: the row groups of one (request, heads)
   // item are dispatched back to back AND on the same XCD (workgroups are dealt round-robin over the 8 XCDs),
   // so the extra row groups of a long (suffix) draft re-read their KV through that XCD's L2 instead of HBM;
@@ -182,7 +193,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ ==
   if (item >= P.n_items) return;
   const int ridx = item / hgroups;
   const int req = P.req_list ? P.req_list[ridx] : ridx;
-  const int h = WH ? (item - ridx * hgroups) * 4 + wave : item - ridx * hgroups;
+  const int h = WH ? (item - ridx * hgroups) * NW + wave : item - ridx * hgroups;
   const int q0 = P.query_start_loc[req];
   const int q_len = P.query_start_loc[req + 1] - q0;
   const int ctx = P.seq_lens[req];
@@ -409,6 +420,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ ==
         float* mp = P.ws_ml + (static_cast<int64_t>(blockIdx.y) * P.total_rows + grow) * 2;
         mp[0] = m_run[mt] * kLn2;  // the combine kernel works in natural-log units
         mp[1] = l_run[mt];
+        if (blockIdx.y == 0) mark_unused_parts(P, grow);
       }
     }
     return;
@@ -477,6 +489,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTQ ==
       float* mp = P.ws_ml + (static_cast<int64_t>(bpart) * P.total_rows + grow) * 2;
       mp[0] = m_all[mt] * kLn2;
       mp[1] = l_all[mt];
+      if (blockIdx.y == 0) mark_unused_parts(P, grow);
     }
   }
 }
@@ -668,6 +681,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
       float* mp = P.ws_ml + (static_cast<int64_t>(blockIdx.y) * P.total_rows + grow) * 2;
       mp[0] = m_run[mt] * kLn2;
       mp[1] = l_run[mt];
+      if (blockIdx.y == 0) mark_unused_parts(P, grow);
     }
   }
 }
@@ -721,17 +735,29 @@ static int side_stream(SideStream** out) {
   return AIC_OK;
 }
 
-static int pick_splits(int batch, int num_kv_heads, int m_groups, int max_seq_len, bool wave_heads) {
-  // waves per split: one per kv head (wave_heads) or four per kv head (token range split over the waves)
-  const int64_t base_waves = static_cast<int64_t>(batch) * num_kv_heads * m_groups * (wave_heads ? 1 : 4);
-  static const int64_t target = []() { const char* e = getenv("AIC_ATTN_WAVES"); return e ? atoll(e) : 4608LL; }();
-  int64_t s = (target + base_waves - 1) / base_waves;  // default: ~2 rounds of 3 waves per SIMD chip-wide
+// Token-range splits per (request, head group) item.  Measured on MI355X (B=64, ctx 4096): what matters is
+// not occupancy but BALANCE — the grid should be an exact multiple of the 256 CUs and fit one residency round
+// (256 workgroups = one 4-wave workgroup per CU ran 190 us; 1152 workgroups = 1.5 rounds of 3 per CU 225 us),
+// and fewer splits also mean fewer partials to write and merge.  So: the smallest split count that gives every
+// CU a workgroup, rounded so the grid is a multiple of the CU count when the batch allows it.
+static int pick_splits(int n_items, int max_seq_len, int min_tiles_per_split) {
+  static const int64_t forced = []() { const char* e = getenv("AIC_ATTN_WAVES"); return e ? atoll(e) : 0LL; }();
+  constexpr int kCUs = 256;
   const int max_tiles = (max_seq_len + kTile - 1) / kTile;
-  const int64_t cap = std::max(1, wave_heads ? (max_tiles + 1) / 2 : (max_tiles + 7) / 8);  // >= ~2 tiles per wave
+  int cap = std::max(1, max_tiles / std::max(1, min_tiles_per_split));
+  if (cap > 64) cap = 64;
+  int s;
+  if (forced > 0) {
+    s = static_cast<int>((forced / 4 + n_items - 1) / n_items);
+  } else if (n_items >= kCUs) {
+    s = 1;
+  } else {
+    s = (kCUs + n_items - 1) / n_items;              // >= one workgroup per CU
+    if ((n_items * s) % kCUs != 0 && n_items * (s - 1) >= kCUs * 15 / 16) --s;  // 240 of 256 CUs beats 1.2 rounds
+  }
   if (s > cap) s = cap;
-  if (s > 64) s = 64;
   if (s < 1) s = 1;
-  return static_cast<int>(s);
+  return s;
 }
 
 }  // namespace aic
@@ -784,11 +810,16 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   const int G = num_q_heads / num_kv_heads;
   const int max_rows = max_q_len * G;
   const bool wave_heads = num_kv_heads % 4 == 0;
-  int n_splits = pick_splits(batch, num_kv_heads, 1, max_seq_len, wave_heads);
+  const int hgroups = wave_heads ? num_kv_heads / 4 : num_kv_heads;
   const size_t rows = static_cast<size_t>(num_tokens) * num_q_heads;
-  while (n_splits > 1 && static_cast<size_t>(n_splits) * rows * (kD + 2) * sizeof(float) > workspace_bytes) --n_splits;
-  AIC_REQUIRE(static_cast<size_t>(n_splits) * rows * (kD + 2) * sizeof(float) <= workspace_bytes,
-              "workspace too small (%zu bytes)", workspace_bytes);
+  // splits of the short / generic launch and of the long-draft launch (its items are few: more splits)
+  int n_splits = pick_splits((split_lists ? std::max(n_short, 1) : batch) * hgroups, max_seq_len, wave_heads ? 2 : 8);
+  int n_splits_long = (split_lists && n_long > 0) ? pick_splits(n_long * num_kv_heads, max_seq_len, 2) : 0;
+  auto fits = [&](int parts) { return static_cast<size_t>(parts) * rows * (kD + 2) * sizeof(float) <= workspace_bytes; };
+  while (n_splits > 1 && !fits(n_splits)) --n_splits;
+  while (n_splits_long > 1 && !fits(n_splits_long)) --n_splits_long;
+  AIC_REQUIRE(fits(n_splits), "workspace too small (%zu bytes)", workspace_bytes);
+  const int n_parts_total = std::max(n_splits, n_splits_long);
 
   AttnParams P;
   P.q = static_cast<const uint16_t*>(q);
@@ -798,7 +829,7 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   P.seq_lens = seq_lens;
   P.query_start_loc = query_start_loc;
   P.ws_o = static_cast<float*>(workspace);
-  P.ws_ml = P.ws_o + static_cast<size_t>(n_splits) * rows * kD;
+  P.ws_ml = P.ws_o + static_cast<size_t>(n_parts_total) * rows * kD;
   P.q_stride = q_stride;
   P.block_stride = block_stride;
   P.max_blocks = max_blocks_per_seq;
@@ -806,6 +837,7 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   P.num_kv_heads = num_kv_heads;
   P.block_size = block_size;
   P.n_splits = n_splits;
+  P.n_parts_total = n_parts_total;
   P.total_rows = static_cast<int>(rows);
   P.sm_scale = sm_scale;
   P.req_list = nullptr;
@@ -813,7 +845,6 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   P.v_scale = v_scale;
 
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int hgroups = wave_heads ? num_kv_heads / 4 : num_kv_heads;
   int rc;
   profile_begin(s);
   if (!split_lists) {
@@ -852,7 +883,8 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
       AttnParams PL = P;
       PL.req_list = long_reqs;
       const int per_block_rows = 4 * kLongTilesPerWave * 16;
-      dim3 grid(static_cast<unsigned>(n_long * num_kv_heads), n_splits, (max_rows + per_block_rows - 1) / per_block_rows);
+      PL.n_splits = n_splits_long;
+      dim3 grid(static_cast<unsigned>(n_long * num_kv_heads), n_splits_long, (max_rows + per_block_rows - 1) / per_block_rows);
       if (kv8)
         hipLaunchKernelGGL(verify_attn_long_kernel<true>, grid, dim3(256), 0, overlap ? side->stream : s, PL);
       else
@@ -864,7 +896,13 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
       P.m_groups = 1;
       P.n_items = n_short * hgroups;
       dim3 grid(static_cast<unsigned>((P.n_items + 7) / 8 * 8), n_splits, 1);
-      if (wave_heads) {
+      static const bool eight = []() { const char* e = getenv("AIC_ATTN_NW8"); return e && e[0] == '1'; }();
+      if (wave_heads && eight && !kv8 && num_kv_heads % 8 == 0) {
+        // experiment: 8 waves = 8 kv heads per workgroup -> whole 2 KiB token rows per workgroup
+        P.n_items = n_short * (num_kv_heads / 8);
+        dim3 grid8(static_cast<unsigned>((P.n_items + 7) / 8 * 8), n_splits, 1);
+        hipLaunchKernelGGL((verify_attn_kernel<1, true, false, 8>), grid8, dim3(512), 0, s, P);
+      } else if (wave_heads) {
         AIC_ATTN_LAUNCH(1, true)
       } else {
         AIC_ATTN_LAUNCH(1, false)
@@ -876,7 +914,7 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   profile_end(s);
   if ((rc = launch_status("verify_attn_kernel")) != AIC_OK) return rc;
   hipLaunchKernelGGL(verify_attn_combine_kernel, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s, P.ws_o,
-                     P.ws_ml, n_splits, static_cast<int>(rows), num_q_heads, static_cast<uint16_t*>(out), out_stride);
+                     P.ws_ml, n_parts_total, static_cast<int>(rows), num_q_heads, static_cast<uint16_t*>(out), out_stride);
   return launch_status("verify_attn_combine_kernel");
 }
 

@@ -27,7 +27,7 @@ def timeit(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) / iters * 1e3  # us
 
 
-def attn(B=64, ctx=4096, qlen=4, Hq=32, Hkv=8, D=128, bs=16, layers=4):
+def attn(B=64, ctx=4096, qlen=4, Hq=32, Hkv=8, D=128, bs=16, layers=4, split=False):
     nblk = (ctx + bs - 1) // bs
     nb = B * nblk
     kvs = [torch.randn(2, nb, bs, Hkv, D, device=dev, dtype=torch.bfloat16) for _ in range(layers)]
@@ -37,12 +37,14 @@ def attn(B=64, ctx=4096, qlen=4, Hq=32, Hkv=8, D=128, bs=16, layers=4):
     seq = torch.full((B,), ctx, dtype=torch.int32, device=dev)
     qsl = (torch.arange(B + 1, device=dev) * qlen).to(torch.int32)
     out = torch.empty_like(q)
+    # split=True: go through the request-list path (all requests short) like the engine does
+    rs = (torch.arange(B, dtype=torch.int32, device=dev), B, None, 0) if split else None
     i = [0]
 
     def f():
         kv = kvs[i[0] % layers]
         i[0] += 1
-        ops.verify_attention(q, kv[0], kv[1], bt, seq, qsl, qlen, ctx, D ** -0.5, out=out)
+        ops.verify_attention(q, kv[0], kv[1], bt, seq, qsl, qlen, ctx, D ** -0.5, out=out, req_split=rs)
     us = timeit(f)
     gb = B * ctx * 2 * Hkv * D * 2 / 1e9
     print(f"attn B={B} ctx={ctx} qlen={qlen} Hq={Hq} Hkv={Hkv}: {us:8.1f} us  {gb / us * 1e6 / 1e3:6.2f} TB/s (incl. combine)")
@@ -76,6 +78,7 @@ def rejection(B=64, k=3, V=128256):
 if __name__ == "__main__":
     what = sys.argv[1:] or ["attn", "lstm", "rej"]
     if "attn" in what:
+        attn(split=True)
         attn()
         attn(B=32)
         attn(B=8)
