@@ -496,16 +496,19 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((M
 
 
 // ------------------------------------------------------------------------------------------------------
-// Long-draft variant (suffix drafts: up to 33 query positions = 132 rows at G = 4).  The four waves of a
-// workgroup stream the SAME tokens of ONE kv head; the 32-token K/V tile is loaded once per workgroup
-// (row-contiguous, 16 B per lane) into a double-buffered LDS image and every wave runs its own row tiles
-// (wave w owns row tiles w, w+4, w+8 -> up to 192 rows per workgroup) against it, so the KV bytes of a long
-// request are read once instead of once per row group.  One barrier per tile.
+// Long-draft variant (suffix drafts: up to 33 query positions = 132 rows at G = 4).  A workgroup is 8 waves on
+// ONE kv head and one token range: waves 0-3 compute, each on its own row tiles (wave w owns row tiles
+// w, w+4, w+8 -> up to 192 rows per workgroup) against a 32-token K/V tile in LDS, so the KV bytes of a long
+// request are read once instead of once per row group; waves 4-7 only move data: they keep THREE tiles in
+// flight in a ring of register sets (row-contiguous 16-byte loads) and drop one tile per iteration into the
+// free half of a double-buffered LDS image (dequantising an fp8 cache on the way).  The compute waves never
+// wait on HBM; with the loads issued by the compute waves themselves (one tile ahead) the kernel ran at HBM
+// latency per tile (~5 us) although its MFMA work per tile is ~0.5 us.  One barrier per tile.
 // ------------------------------------------------------------------------------------------------------
 constexpr int kLongTilesPerWave = 3;
 
 template <bool KV8>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) verify_attn_long_kernel(AttnParams P) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) verify_attn_long_kernel(AttnParams P) {
   constexpr int RT = kLongTilesPerWave;
   __shared__ uint4 kv_lds[2][2][kTile * 16];  // [buffer][K|V][32 tokens x 16 chunks]
 
@@ -527,17 +530,92 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int tiles_per_part = (tiles_total + P.n_splits - 1) / P.n_splits;
   const int t_begin = blockIdx.y * tiles_per_part * kTile;
   const int t_end = min(ctx, t_begin + tiles_per_part * kTile);
+  const int n_iter = t_begin < t_end ? (t_end - t_begin + kTile - 1) / kTile : 0;
 
   const int64_t kv_row = static_cast<int64_t>(Hkv) * kD;
   const int32_t* btab = P.block_table + static_cast<int64_t>(req) * P.max_blocks;
   const int bs = P.block_size;
   const int last_group = (ctx - 1) & ~15;
+
+  if (wave >= 4) {
+    // ================================ loader waves ================================
+    const char* kc = reinterpret_cast<const char*>(P.k_cache);
+    const char* vc = reinterpret_cast<const char*>(P.v_cache);
+    const int lt = threadIdx.x - 256;
+    // bf16: thread moves 16-byte chunks lt and lt + 256 of K and of V (token = chunk / 16);
+    // fp8 : the tile is 256 chunks of 16 bytes, one per thread (token = lt / 8), dequantised at the LDS store
+    const int tk0 = KV8 ? lt >> 3 : lt >> 4, tk1 = tk0 + 16;
+    const int ch = KV8 ? lt & 7 : lt & 15;
+    uint4 ak0, ak1, av0, av1, bk0, bk1, bv0, bv1, ck0, ck1, cv0, cv1;
+    if (KV8) ak1 = av1 = bk1 = bv1 = ck1 = cv1 = make_uint4(0, 0, 0, 0);
+#define AIC_LONG_LOAD(set_, tt_)                                                                                \
+  {                                                                                                             \
+    const int f0_ = min((tt_), last_group), f1_ = min((tt_) + 16, last_group);                                  \
+    const int64_t b0_ = static_cast<int64_t>(btab[f0_ / bs]) * P.block_stride + static_cast<int64_t>(f0_ % bs) * kv_row + h * kD; \
+    const int64_t b1_ = static_cast<int64_t>(btab[f1_ / bs]) * P.block_stride + static_cast<int64_t>(f1_ % bs) * kv_row + h * kD; \
+    if (KV8) {                                                                                                  \
+      const bool hi_ = tk0 >= 16;                                                                               \
+      const int64_t o_ = (hi_ ? b1_ : b0_) + static_cast<int64_t>(min((tt_) + tk0, ctx - 1) - (hi_ ? f1_ : f0_)) * kv_row + 16 * ch; \
+      set_##k0 = *reinterpret_cast<const uint4*>(kc + o_);                                                      \
+      set_##v0 = *reinterpret_cast<const uint4*>(vc + o_);                                                      \
+    } else {                                                                                                    \
+      const int64_t o0_ = b0_ + static_cast<int64_t>(min((tt_) + tk0, ctx - 1) - f0_) * kv_row + 8 * ch;       \
+      const int64_t o1_ = b1_ + static_cast<int64_t>(min((tt_) + tk1, ctx - 1) - f1_) * kv_row + 8 * ch;       \
+      set_##k0 = *reinterpret_cast<const uint4*>(kc + 2 * o0_);                                                 \
+      set_##k1 = *reinterpret_cast<const uint4*>(kc + 2 * o1_);                                                 \
+      set_##v0 = *reinterpret_cast<const uint4*>(vc + 2 * o0_);                                                 \
+      set_##v1 = *reinterpret_cast<const uint4*>(vc + 2 * o1_);                                                 \
+    }                                                                                                           \
+  }
+#define AIC_LONG_STORE(set_, buf_)                                                                              \
+  {                                                                                                             \
+    char* kb_ = reinterpret_cast<char*>(kv_lds[buf_][0]);                                                       \
+    char* vb_ = reinterpret_cast<char*>(kv_lds[buf_][1]);                                                       \
+    if (KV8) {                                                                                                  \
+      *reinterpret_cast<bf16x8*>(kb_ + v_tile_off(tk0, 2 * ch)) = fp8x8_to_bf16x8(set_##k0.x, set_##k0.y);      \
+      *reinterpret_cast<bf16x8*>(kb_ + v_tile_off(tk0, 2 * ch + 1)) = fp8x8_to_bf16x8(set_##k0.z, set_##k0.w);  \
+      *reinterpret_cast<bf16x8*>(vb_ + v_tile_off(tk0, 2 * ch)) = fp8x8_to_bf16x8(set_##v0.x, set_##v0.y);      \
+      *reinterpret_cast<bf16x8*>(vb_ + v_tile_off(tk0, 2 * ch + 1)) = fp8x8_to_bf16x8(set_##v0.z, set_##v0.w);  \
+    } else {                                                                                                    \
+      *reinterpret_cast<uint4*>(kb_ + v_tile_off(tk0, ch)) = set_##k0;                                          \
+      *reinterpret_cast<uint4*>(kb_ + v_tile_off(tk1, ch)) = set_##k1;                                          \
+      *reinterpret_cast<uint4*>(vb_ + v_tile_off(tk0, ch)) = set_##v0;                                          \
+      *reinterpret_cast<uint4*>(vb_ + v_tile_off(tk1, ch)) = set_##v1;                                          \
+    }                                                                                                           \
+  }
+    // tile j of the range starts at token t_begin + 32 j; loads past the range are clamped into the context
+    // (valid addresses, never consumed)
+#define AIC_TILE(j_) (t_begin + (j_) * kTile)
+    if (n_iter > 0) {
+      AIC_LONG_LOAD(a, AIC_TILE(0))
+      AIC_LONG_STORE(a, 0)
+      AIC_LONG_LOAD(a, AIC_TILE(1))
+      AIC_LONG_LOAD(b, AIC_TILE(2))
+      AIC_LONG_LOAD(c, AIC_TILE(3))
+    }
+    // iteration i: (barrier) tile i+1 -> LDS buffer (i+1)&1, then re-arm that register set with tile i+4
+    for (int i = 0; i < n_iter; i += 3) {
+      __syncthreads();
+      if (i + 1 < n_iter) AIC_LONG_STORE(a, (i + 1) & 1)
+      AIC_LONG_LOAD(a, AIC_TILE(i + 4))
+      if (i + 1 >= n_iter) break;
+      __syncthreads();
+      if (i + 2 < n_iter) AIC_LONG_STORE(b, (i + 2) & 1)
+      AIC_LONG_LOAD(b, AIC_TILE(i + 5))
+      if (i + 2 >= n_iter) break;
+      __syncthreads();
+      if (i + 3 < n_iter) AIC_LONG_STORE(c, (i + 3) & 1)
+      AIC_LONG_LOAD(c, AIC_TILE(i + 6))
+    }
+#undef AIC_TILE
+#undef AIC_LONG_LOAD
+#undef AIC_LONG_STORE
+    return;
+  }
+
+  // ================================ compute waves ================================
   const float scale_log2 = P.sm_scale * kLog2e * (KV8 ? *P.k_scale : 1.0f);
   const float out_scale = KV8 ? *P.v_scale : 1.0f;
-  const char* kc = reinterpret_cast<const char*>(P.k_cache);
-  const char* vc = reinterpret_cast<const char*>(P.v_cache);
-
-  // query fragments of this wave's row tiles
   uint4 qf[RT][4];
   int row_pos[RT];
   bool row_ok[RT];
@@ -562,108 +640,56 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int dt = 0; dt < 8; ++dt) o_acc[mt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  // cooperative tile load.  bf16: thread t moves 16-byte chunks t and t + 256 of K and of V (token = chunk / 16);
-  // fp8: the tile is 256 chunks of 16 bytes, one per thread (token = t / 8), dequantised to bf16 at the LDS store
-  const int tk0 = KV8 ? threadIdx.x >> 3 : threadIdx.x >> 4, tk1 = tk0 + 16;
-  const int ch = KV8 ? threadIdx.x & 7 : threadIdx.x & 15;
-  uint4 rk0, rk1, rv0, rv1;
-  if (KV8) rk1 = rv1 = make_uint4(0, 0, 0, 0);
-#define AIC_LONG_LOAD(tt_)                                                                                      \
-  {                                                                                                             \
-    const int f0_ = min((tt_), last_group), f1_ = min((tt_) + 16, last_group);                                  \
-    const int64_t b0_ = static_cast<int64_t>(btab[f0_ / bs]) * P.block_stride + static_cast<int64_t>(f0_ % bs) * kv_row + h * kD; \
-    const int64_t b1_ = static_cast<int64_t>(btab[f1_ / bs]) * P.block_stride + static_cast<int64_t>(f1_ % bs) * kv_row + h * kD; \
-    if (KV8) {                                                                                                  \
-      const bool hi_ = tk0 >= 16;                                                                               \
-      const int64_t o_ = (hi_ ? b1_ : b0_) + static_cast<int64_t>(min((tt_) + tk0, ctx - 1) - (hi_ ? f1_ : f0_)) * kv_row + 16 * ch; \
-      rk0 = *reinterpret_cast<const uint4*>(kc + o_);                                                           \
-      rv0 = *reinterpret_cast<const uint4*>(vc + o_);                                                           \
-    } else {                                                                                                    \
-      const int64_t o0_ = b0_ + static_cast<int64_t>(min((tt_) + tk0, ctx - 1) - f0_) * kv_row + 8 * ch;       \
-      const int64_t o1_ = b1_ + static_cast<int64_t>(min((tt_) + tk1, ctx - 1) - f1_) * kv_row + 8 * ch;       \
-      rk0 = *reinterpret_cast<const uint4*>(kc + 2 * o0_);                                                      \
-      rk1 = *reinterpret_cast<const uint4*>(kc + 2 * o1_);                                                      \
-      rv0 = *reinterpret_cast<const uint4*>(vc + 2 * o0_);                                                      \
-      rv1 = *reinterpret_cast<const uint4*>(vc + 2 * o1_);                                                      \
-    }                                                                                                           \
-  }
-#define AIC_LONG_STORE(buf_)                                                                                    \
-  {                                                                                                             \
-    char* kb_ = reinterpret_cast<char*>(kv_lds[buf_][0]);                                                       \
-    char* vb_ = reinterpret_cast<char*>(kv_lds[buf_][1]);                                                       \
-    if (KV8) {                                                                                                  \
-      *reinterpret_cast<bf16x8*>(kb_ + v_tile_off(tk0, 2 * ch)) = fp8x8_to_bf16x8(rk0.x, rk0.y);                \
-      *reinterpret_cast<bf16x8*>(kb_ + v_tile_off(tk0, 2 * ch + 1)) = fp8x8_to_bf16x8(rk0.z, rk0.w);            \
-      *reinterpret_cast<bf16x8*>(vb_ + v_tile_off(tk0, 2 * ch)) = fp8x8_to_bf16x8(rv0.x, rv0.y);                \
-      *reinterpret_cast<bf16x8*>(vb_ + v_tile_off(tk0, 2 * ch + 1)) = fp8x8_to_bf16x8(rv0.z, rv0.w);            \
-    } else {                                                                                                    \
-      *reinterpret_cast<uint4*>(kb_ + v_tile_off(tk0, ch)) = rk0;                                               \
-      *reinterpret_cast<uint4*>(kb_ + v_tile_off(tk1, ch)) = rk1;                                               \
-      *reinterpret_cast<uint4*>(vb_ + v_tile_off(tk0, ch)) = rv0;                                               \
-      *reinterpret_cast<uint4*>(vb_ + v_tile_off(tk1, ch)) = rv1;                                               \
-    }                                                                                                           \
-  }
+  for (int it = 0; it < n_iter; ++it) {
+    const int tt = t_begin + it * kTile;
+    const int buf = it & 1;
+    __syncthreads();  // buffer `buf` is complete; the loaders may now overwrite buffer buf ^ 1
+    const char* kb = reinterpret_cast<const char*>(kv_lds[buf][0]);
+    const char* vb = reinterpret_cast<const char*>(kv_lds[buf][1]);
+    // K fragments of the tile (A operand of S^T = K Q^T): lane (token c16 [+16], d = 32 s + 8 g)
+    uint4 kf[2][4];
+#pragma unroll
+    for (int th = 0; th < 2; ++th)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kf[th][s] = *reinterpret_cast<const uint4*>(kb + v_tile_off(16 * th + c16, 4 * s + g));
 
-  if (t_begin < t_end) {
-    // tile t+1 sits in registers while tile t is computed and is written to the other LDS buffer at the TOP of
-    // the next iteration, so every global load has a whole iteration of MFMA work to land under
-    AIC_LONG_LOAD(t_begin)
-    AIC_LONG_STORE(0)
-    AIC_LONG_LOAD(t_begin + kTile)
-    int buf = 0;
-    for (int tt = t_begin; tt < t_end; tt += kTile, buf ^= 1) {
-      __syncthreads();  // buffer `buf` is complete; every wave is done with buffer buf ^ 1
-      if (tt + kTile < t_end) AIC_LONG_STORE(buf ^ 1)
-      AIC_LONG_LOAD(tt + 2 * kTile)  // clamped into the context: always valid; unused past the range
-      const char* kb = reinterpret_cast<const char*>(kv_lds[buf][0]);
-      const char* vb = reinterpret_cast<const char*>(kv_lds[buf][1]);
-      // K fragments of the tile (A operand of S^T = K Q^T): lane (token c16 [+16], d = 32 s + 8 g)
-      uint4 kf[2][4];
+    bf16x8 pfrag[RT], pfrag_lo[RT];
+    const bool need_mask = tt + kTile > t_end || tt + kTile > ctx - q_len + 1;
 #pragma unroll
-      for (int th = 0; th < 2; ++th)
+    for (int mt = 0; mt < RT; ++mt) {
+      f32x4 st[2];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) kf[th][s] = *reinterpret_cast<const uint4*>(kb + v_tile_off(16 * th + c16, 4 * s + g));
-
-      bf16x8 pfrag[RT], pfrag_lo[RT];
-      const bool need_mask = tt + kTile > t_end || tt + kTile > ctx - q_len + 1;
+      for (int th = 0; th < 2; ++th) {
+        st[th] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int mt = 0; mt < RT; ++mt) {
-        f32x4 st[2];
-#pragma unroll
-        for (int th = 0; th < 2; ++th) {
-          st[th] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-            st[th] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[th][s]),
-                                                             __builtin_bit_cast(bf16x8, qf[mt][s]), st[th], 0, 0, 0);
-        }
-        softmax_tile(st[0], st[1], need_mask, row_ok[mt], tt, g, t_end, ctx - q_len + row_pos[mt], scale_log2, m_run[mt],
-                     l_run[mt], o_acc[mt], pfrag[mt], pfrag_lo[mt]);
+        for (int s = 0; s < 4; ++s)
+          st[th] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[th][s]),
+                                                           __builtin_bit_cast(bf16x8, qf[mt][s]), st[th], 0, 0, 0);
       }
-      {
-        const int q4 = c16 >> 2, p4 = c16 & 3;
+      softmax_tile(st[0], st[1], need_mask, row_ok[mt], tt, g, t_end, ctx - q_len + row_pos[mt], scale_log2, m_run[mt],
+                   l_run[mt], o_acc[mt], pfrag[mt], pfrag_lo[mt]);
+    }
+    {
+      const int q4 = c16 >> 2, p4 = c16 & 3;
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
-          const char* a_lo = vb + v_tile_off(4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
-          const char* a_hi = vb + v_tile_off(16 + 4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(a_lo)));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(a_hi)));
-          typedef __attribute__((ext_vector_type(8))) short s16x8;
-          const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          const bf16x8 vfrag = __builtin_bit_cast(bf16x8, both);
+      for (int dt = 0; dt < 8; ++dt) {
+        const char* a_lo = vb + v_tile_off(4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
+        const char* a_hi = vb + v_tile_off(16 + 4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(a_lo)));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(a_hi)));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 vfrag = __builtin_bit_cast(bf16x8, both);
 #pragma unroll
-          for (int mt = 0; mt < RT; ++mt) {
-            o_acc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pfrag[mt], o_acc[mt][dt], 0, 0, 0);
-            o_acc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pfrag_lo[mt], o_acc[mt][dt], 0, 0, 0);
-          }
+        for (int mt = 0; mt < RT; ++mt) {
+          o_acc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pfrag[mt], o_acc[mt][dt], 0, 0, 0);
+          o_acc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pfrag_lo[mt], o_acc[mt][dt], 0, 0, 0);
         }
       }
     }
   }
-#undef AIC_LONG_LOAD
-#undef AIC_LONG_STORE
 
 #pragma unroll
   for (int mt = 0; mt < RT; ++mt) {
@@ -814,7 +840,7 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   const size_t rows = static_cast<size_t>(num_tokens) * num_q_heads;
   // splits of the short / generic launch and of the long-draft launch (its items are few: more splits)
   int n_splits = pick_splits((split_lists ? std::max(n_short, 1) : batch) * hgroups, max_seq_len, wave_heads ? 2 : 8);
-  int n_splits_long = (split_lists && n_long > 0) ? pick_splits(n_long * num_kv_heads, max_seq_len, 2) : 0;
+  int n_splits_long = (split_lists && n_long > 0) ? pick_splits(n_long * num_kv_heads, max_seq_len, 16) : 0;
   auto fits = [&](int parts) { return static_cast<size_t>(parts) * rows * (kD + 2) * sizeof(float) <= workspace_bytes; };
   while (n_splits > 1 && !fits(n_splits)) --n_splits;
   while (n_splits_long > 1 && !fits(n_splits_long)) --n_splits_long;
@@ -886,9 +912,9 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
       PL.n_splits = n_splits_long;
       dim3 grid(static_cast<unsigned>(n_long * num_kv_heads), n_splits_long, (max_rows + per_block_rows - 1) / per_block_rows);
       if (kv8)
-        hipLaunchKernelGGL(verify_attn_long_kernel<true>, grid, dim3(256), 0, overlap ? side->stream : s, PL);
+        hipLaunchKernelGGL(verify_attn_long_kernel<true>, grid, dim3(512), 0, overlap ? side->stream : s, PL);
       else
-        hipLaunchKernelGGL(verify_attn_long_kernel<false>, grid, dim3(256), 0, overlap ? side->stream : s, PL);
+        hipLaunchKernelGGL(verify_attn_long_kernel<false>, grid, dim3(512), 0, overlap ? side->stream : s, PL);
       if (overlap) AIC_HIP_TRY(hipEventRecord(side->join, side->stream));
     }
     if (n_short > 0) {

@@ -39,6 +39,8 @@ def attn(B=64, ctx=4096, qlen=4, Hq=32, Hkv=8, D=128, bs=16, layers=4, split=Fal
     out = torch.empty_like(q)
     # split=True: go through the request-list path (all requests short) like the engine does
     rs = (torch.arange(B, dtype=torch.int32, device=dev), B, None, 0) if split else None
+    if split and qlen * (Hq // Hkv) > 16:
+        rs = ops.split_requests([qlen] * B, Hq // Hkv, dev)
     i = [0]
 
     def f():
@@ -84,6 +86,9 @@ if __name__ == "__main__":
         attn(B=8)
         attn(B=64, Hq=4, Hkv=1)        # SP=8 slice
         attn(B=64, qlen=8)
+        attn(B=16, qlen=33, split=True)
+        attn(B=4, qlen=33, split=True)
+        attn(B=1, qlen=33, split=True)
     if "lstm" in what:
         lstm(64)
         lstm(32)
