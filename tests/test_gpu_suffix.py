@@ -52,10 +52,6 @@ def _replay(cache, cfg, batched):
     prompts = [[int(x) for x in p] for p, _ in reqs]
     gts = [[int(x) for x in g] for _, g in reqs]
     out = []
-    if not batched:
-        order = [[r] for r in range(n_req)]
-    else:
-        order = None
     # sequential per request reproduces the golden digests exactly (the global tree evolves in the same order)
     for r in range(n_req):
         cache.cache_prompt(r, prompts[r])
@@ -135,3 +131,55 @@ def test_batched_step_equals_oracle():
             want = orc.speculate(r, p, max_spec_tokens=32)
             gu.assert_cand(got, gu.cand_dict(want), ctx=f"step {step} req {r}")
     assert dev._global_tree().selfcheck() == 0
+
+
+@pytest.mark.parametrize("depth", [3, 17, 128])
+def test_device_matches_oracle_other_depths(depth):
+    """max_depth other than 64: more than 64 suffix starts per query (the select kernel strides its lanes),
+    budgets up to max_depth - 1, pool / hash growth in the HBM mirror while the tree grows."""
+    from oracle.suffix_oracle import OracleSuffixTree
+    rng = random.Random(depth)
+    dev, orc = SuffixTree(depth), OracleSuffixTree(depth)
+    vocab = 6 if depth > 16 else 3
+    hist = {s: [] for s in range(3)}
+    n = 0
+    for step in range(1500 if depth > 16 else 300):
+        s = rng.randrange(3)
+        toks = [rng.randrange(vocab) for _ in range(rng.randint(1, 5))]
+        dev.extend(s, toks)
+        orc.extend(s, toks)
+        hist[s].extend(toks)
+        if step % 25 == 0:
+            src = hist[rng.randrange(3)]
+            if not src:
+                continue
+            pat = src[-rng.randint(1, min(len(src), depth + 5)):]
+            args = (rng.choice([1, 8, depth, 2 * depth]), rng.choice([1.0, 2.0, 8.0]), rng.choice([0.0, 3.0]),
+                    rng.choice([0.0, 0.05, 0.2]))
+            gu.assert_cand(dev.speculate(pat, *args), gu.cand_dict(orc.speculate(pat, *args)), ctx=f"step {step}")
+            n += 1
+    assert n > 10 and dev.selfcheck() == 0
+
+
+def test_device_large_batch_of_queries():
+    """256 queries in one round trip (more than one residency of 4-wave blocks), prompt + global trees."""
+    from oracle.suffix_oracle import OracleSuffixCache
+    src = TokenSource(vocab_size=500, seed=9, n_motifs=10, motif_min=4, motif_max=10, p_motif=0.6)
+    B = 256
+    dev, orc = SuffixCache(32), OracleSuffixCache(32)
+    rows = []
+    for r in range(B):
+        p, g = src.request(r, 48, 24)
+        rows.append([int(x) for x in p] + [int(x) for x in g])
+        for c in (dev, orc):
+            c.cache_prompt(r, rows[r][:48])
+            c.update_response(r, rows[r][48:60])
+    res = dev.speculate_batch(list(range(B)), [r[:60] for r in rows], [16] * B, [2.0] * B, [1.0] * B, [0.05] * B,
+                              [i % 3 != 0 for i in range(B)])
+    hits = 0
+    for r in range(B):
+        want = orc.speculate(r, rows[r][:60], max_spec_tokens=16, max_spec_factor=2.0, max_spec_offset=1.0,
+                             min_token_prob=0.05, use_cached_prompt=(r % 3 != 0))
+        gu.assert_cand(res[r], gu.cand_dict(want), ctx=f"req {r}")
+        hits += len(want.token_ids) > 0
+    assert hits > 100
