@@ -151,10 +151,13 @@ class UlyssesAttention:
     kernels; the CPU (gloo) tests inject torch expressions so the group / index logic runs without a GPU."""
 
     def __init__(self, sp_size: int, group, num_q_heads_local: int, num_kv_heads_local: int, head_size: int,
-                 pack: Callable = _hip_pack, unpack: Callable = _hip_unpack):
+                 pack: Callable = _hip_pack, unpack: Callable = _hip_unpack, all_to_all: Optional[Callable] = None):
         self.sp_size, self.group = sp_size, group
         self.hq, self.hkv, self.D = num_q_heads_local, num_kv_heads_local, head_size
         self.pack, self.unpack = pack, unpack
+        # `all_to_all(recv, send)`: torch.distributed over the SP group unless a stand-in is injected (the
+        # single-GPU shape rehearsal of bench.py --rehearse-sp copies send to recv)
+        self._a2a = all_to_all
 
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, attn: Callable) -> torch.Tensor:
         import torch.distributed as dist
@@ -163,11 +166,17 @@ class UlyssesAttention:
         qw, kw = self.hq * self.D, self.hkv * self.D
         send = self.pack(query, key, value, self.sp_size)               # [SP*n, qw + 2kw], rank-major
         recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=self.group)            # C1 (ulysses.py:502)
+        if self._a2a is not None:
+            self._a2a(recv, send)
+        else:
+            dist.all_to_all_single(recv, send, group=self.group)        # C1 (ulysses.py:502)
         q_, k_, v_ = recv[:, :qw], recv[:, qw:qw + kw], recv[:, qw + kw:]
         c_ = attn(q_, k_, v_)                                           # all N tokens, local heads
         c = torch.empty_like(c_)
-        dist.all_to_all_single(c, c_, group=self.group)                 # C2 (ulysses.py:514)
+        if self._a2a is not None:
+            self._a2a(c, c_)
+        else:
+            dist.all_to_all_single(c, c_, group=self.group)             # C2 (ulysses.py:514)
         return self.unpack(c, self.sp_size)                             # [n, SP*qw]
 
 
@@ -175,13 +184,13 @@ class UlyssesContext:
     """SP state of one rank for the stand-alone engine (arcticinference_amd/engine.py): the per-layer
     attention of a step runs on this rank's head slice with the two all-to-alls around it."""
 
-    def __init__(self, sp_size: int, sp_rank: int, group, shape, device="cuda"):
+    def __init__(self, sp_size: int, sp_rank: int, group, shape, device="cuda", all_to_all: Optional[Callable] = None):
         self.sp_size, self.sp_rank, self.group = sp_size, sp_rank, group
         lh = local_heads(shape.num_q_heads, shape.num_kv_heads, sp_size)
         if lh.kv_replicated:
             raise NotImplementedError("KV-replicated Ulysses (Hkv < SP) is not on the MI355X path yet (SURVEY §8f-3)")
         self.heads = lh
-        self.attn = UlyssesAttention(sp_size, group, lh.num_q_heads, lh.num_kv_heads, shape.head_size)
+        self.attn = UlyssesAttention(sp_size, group, lh.num_q_heads, lh.num_kv_heads, shape.head_size, all_to_all=all_to_all)
 
     def attention_layers(self, eng, T, bt, d_seq, d_qsl, max_q, max_ctx) -> None:
         from . import ops

@@ -46,6 +46,9 @@ def parse_args():
     ap.add_argument("--no-lstm", action="store_true")
     ap.add_argument("--kv-dtype", default="auto", choices=["auto", "fp8"], help="KV cache dtype (auto = bf16, the headline config)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--rehearse-sp", type=int, default=0,
+                    help="single-GPU rehearsal of the SP=N code path: real pack/unpack/attention shapes of rank 0, "
+                         "the all-to-all replaced by a local copy (numbers are NOT a multi-GPU measurement)")
     return ap.parse_args()
 
 
@@ -142,6 +145,10 @@ def main():
         from arcticinference_amd.ulysses import UlyssesContext
         ulysses = UlyssesContext(world, rank, dist.group.WORLD, shape, device=dev)
         tp_group = dist.group.WORLD
+
+    if world == 1 and args.rehearse_sp > 1:
+        from arcticinference_amd.ulysses import UlyssesContext
+        ulysses = UlyssesContext(args.rehearse_sp, 0, None, shape, device=dev, all_to_all=lambda recv, send: recv.copy_(send))
 
     drafter = None
     if not args.no_lstm:
@@ -251,7 +258,7 @@ def main():
                              "attention, acceptance, suffix + LSTM proposal, KV write); target dense layers synthetic"
                              % (shape.num_layers, B, PL, GL, "bf16" if args.kv_dtype == "auto" else "fp8 e4m3")),
                 "global_batch": B, "prompt_len": PL, "gen_len": GL,
-                "parallelism": "sp%d" % world if world > 1 else "tp1",
+                "parallelism": ("sp%d" % world if world > 1 else ("tp1" if args.rehearse_sp <= 1 else "REHEARSAL sp%d on one GPU" % args.rehearse_sp)),
             },
             "tokens_per_s_per_gpu": value / world,
             "mean_accepted_draft_len": st.accepted / max(st.num_drafts, 1),
