@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libarctic_hip.so"
-LIB_PATH = os.path.join(_PKG, LIB_NAME)
+LIB_PATH = os.environ.get("AIC_LIB_PATH") or os.path.join(_PKG, LIB_NAME)   # AIC_LIB_PATH: A/B builds while tuning
 CSRC = os.path.join(_PKG, "csrc")
 
 AIC_OK = 0

@@ -202,7 +202,7 @@ def main():
     for _ in range(args.warmup):
         run_step()
     barrier()
-    N.lib().aic_profile_enable(1)
+    N.lib().aic_profile_enable(0 if os.environ.get("AIC_BENCH_NOPROFILE") else 1)
     gen_tokens[0] = 0
     eng.stats = type(eng.stats)()
     eng.timeline = {}
