@@ -24,6 +24,7 @@
 //     back transposed with ds_read_b64_tr_b16 as the MFMA A operand.
 // Partials (m, l, unnormalised O) per (split, wave) go to a workspace; a second kernel merges them.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <algorithm>
 #include <cstdlib>
@@ -68,6 +69,7 @@ struct AttnParams {
   const float* k_scale;     // fp8 KV cache: per-tensor dequantisation scales (device scalars)
   const float* v_scale;
   float sm_scale;
+  int dbg;
 };
 
 // Byte offset of 16-byte chunk `ch` (0..15) of token `t` (0..31) in the wave's V tile.  256-byte rows with
@@ -128,6 +130,81 @@ __device__ __forceinline__ void softmax_tile(const f32x4& s0, const f32x4& s1, b
   psum += __shfl_xor(psum, 16);
   psum += __shfl_xor(psum, 32);
   l_run = l_run * alpha + psum;
+  m_run = m_new;
+  if (!__all(alpha == 1.0f)) {
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) o[dt] *= alpha;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    pf[e] = static_cast<__bf16>(pv[e]);
+    pl[e] = static_cast<__bf16>(pv[e] - static_cast<float>(pf[e]));
+  }
+}
+
+// Lanes c16 + 16 g (g = 0..3) hold the same query row.  gfx950's row / half swaps combine them on the VALU
+// (ds_bpermute costs an LDS round trip per step, and the long-draft kernel is VALU/latency bound).  The
+// s_nops are the VALU-write -> permlane-swap -> VALU-read hazards the assembler does not see inside asm.
+__device__ __forceinline__ void swap16(float& a, float& b) {
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap32(float& a, float& b) {
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float rowgroup_max(float x) {
+  float a = x, b = x;
+  swap16(a, b);
+  a = a > b ? a : b;
+  b = a;
+  swap32(a, b);
+  return a > b ? a : b;
+}
+__device__ __forceinline__ float rowgroup_sum(float x) {
+  float a = x, b = x;
+  swap16(a, b);
+  a += b;
+  b = a;
+  swap32(a, b);
+  return a + b;
+}
+
+// softmax_tile for the long-draft kernel: the scale is folded into the exponent's fma (the maximum is taken on
+// raw scores; m_run is kept scaled), the row sum stays a per-lane partial (rowgroup_sum once, in the epilogue).
+__device__ __forceinline__ void softmax_tile_long(const f32x4& s0, const f32x4& s1, bool need_mask, bool row_ok, int tt,
+                                                  int g, int t_end, int limit, float scale_log2, float& m_run,
+                                                  float& l_part, f32x4 (&o)[8], bf16x8& pf, bf16x8& pl) {
+  float sc[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sc[e] = s0[e];
+    sc[4 + e] = s1[e];
+  }
+  if (need_mask) {
+#pragma unroll
+    for (int th = 0; th < 2; ++th)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int tok = tt + 16 * th + 4 * g + e;
+        if (!(row_ok && tok < t_end && tok <= limit)) sc[th * 4 + e] = -INFINITY;
+      }
+  }
+  const float tmax = rowgroup_max(fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])),
+                                        fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7]))));
+  const float m_new = fmaxf(m_run, tmax * scale_log2);
+  float alpha = 1.0f, psum = 0.0f;
+  float pv[8];
+  if (m_new == -INFINITY) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pv[e] = 0.0f;
+  } else {
+    alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e], scale_log2, -m_new));
+      psum += pv[e];
+    }
+  }
+  l_part = l_part * alpha + psum;
   m_run = m_new;
   if (!__all(alpha == 1.0f)) {
 #pragma unroll
@@ -591,6 +668,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     // tile j of the range starts at token t_begin + 32 j; loads past the range are clamped into the context
     // (valid addresses, never consumed)
 #define AIC_TILE(j_) (t_begin + (j_) * kTile)
+    if (P.dbg & 1) {
+      ak0 = ak1 = av0 = av1 = make_uint4(0, 0, 0, 0);
+      for (int i = 0; i < n_iter; ++i) {
+        __syncthreads();
+        if (i + 1 < n_iter) AIC_LONG_STORE(a, (i + 1) & 1)
+      }
+      return;
+    }
     if (n_iter > 0) {
       AIC_LONG_LOAD(a, AIC_TILE(0))
       AIC_LONG_STORE(a, 0)
@@ -645,36 +730,95 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int dt = 0; dt < 8; ++dt) o_acc[mt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  for (int it = 0; it < n_iter; ++it) {
-    const int tt = t_begin + it * kTile;
-    const int buf = it & 1;
-    __syncthreads();  // buffer `buf` is complete; the loaders may now overwrite buffer buf ^ 1
-    const char* kb = reinterpret_cast<const char*>(kv_lds[buf][0]);
-    const char* vb = reinterpret_cast<const char*>(kv_lds[buf][1]);
-    // K fragments of the tile (A operand of S^T = K Q^T): lane (token c16 [+16], d = 32 s + 8 g)
-    uint4 kf[2][4];
-#pragma unroll
-    for (int th = 0; th < 2; ++th)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) kf[th][s] = *reinterpret_cast<const uint4*>(kb + v_tile_off(16 * th + c16, 4 * s + g));
+  // row tiles this wave really owns (tile index wave + 4 mt < ceil(rows / 16)); the others are skipped
+  const int n_row_tiles = (min(n_rows - row_base, 4 * RT * 16) + 15) >> 4;
+  const int my_tiles = __builtin_amdgcn_readfirstlane(n_row_tiles > wave ? (n_row_tiles - wave + 3) >> 2 : 0);
 
-    bf16x8 pfrag[RT], pfrag_lo[RT];
-    const bool need_mask = tt + kTile > t_end || tt + kTile > ctx - q_len + 1;
+  // One instance of the tile loop per row-tile count NT (wave-uniform), so that its body is straight-line code:
+  // all NT x 8 score MFMAs first, then a branch-free soft-max over the NT tiles (the scale folded into the
+  // exponent's fma, row maxima by VALU lane swaps, row sums kept as per-lane partials), then the PV MFMAs.  With
+  // one soft-max call per row tile the calls' branches kept the MFMA chains and the VALU work of different row
+  // tiles from overlapping, and the wave (alone on its SIMD) ran at the sum of every latency.
+  auto tile_loop = [&](auto nt_tag) {
+    constexpr int NT = decltype(nt_tag)::value;
+    for (int it = 0; it < n_iter; ++it) {
+      const int tt = t_begin + it * kTile;
+      const int buf = it & 1;
+      __syncthreads();  // buffer `buf` is complete; the loaders may now overwrite buffer buf ^ 1
+      if (P.dbg & 2) continue;
+      const char* kb = reinterpret_cast<const char*>(kv_lds[buf][0]);
+      const char* vb = reinterpret_cast<const char*>(kv_lds[buf][1]);
+      // K fragments of the tile (A operand of S^T = K Q^T): lane (token c16 [+16], d = 32 s + 8 g)
+      uint4 kf[2][4];
 #pragma unroll
-    for (int mt = 0; mt < RT; ++mt) {
-      f32x4 st[2];
+      for (int th = 0; th < 2; ++th)
 #pragma unroll
-      for (int th = 0; th < 2; ++th) {
-        st[th] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < 4; ++s) kf[th][s] = *reinterpret_cast<const uint4*>(kb + v_tile_off(16 * th + c16, 4 * s + g));
+
+      f32x4 st[NT][2];
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-          st[th] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[th][s]),
-                                                           __builtin_bit_cast(bf16x8, qf[mt][s]), st[th], 0, 0, 0);
+      for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int th = 0; th < 2; ++th) st[mt][th] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+          for (int th = 0; th < 2; ++th)
+            st[mt][th] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[th][s]),
+                                                                 __builtin_bit_cast(bf16x8, qf[mt][s]), st[mt][th], 0, 0, 0);
+      const bool need_mask = tt + kTile > t_end || tt + kTile > ctx - q_len + 1;
+      if (need_mask) {
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) {
+          const int limit = ctx - q_len + row_pos[mt];
+#pragma unroll
+          for (int th = 0; th < 2; ++th)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int tok = tt + 16 * th + 4 * g + e;
+              if (!(row_ok[mt] && tok < t_end && tok <= limit)) st[mt][th][e] = -INFINITY;
+            }
+        }
       }
-      softmax_tile(st[0], st[1], need_mask, row_ok[mt], tt, g, t_end, ctx - q_len + row_pos[mt], scale_log2, m_run[mt],
-                   l_run[mt], o_acc[mt], pfrag[mt], pfrag_lo[mt]);
-    }
-    {
+      float alpha[NT], m_use[NT];
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt) {
+        const f32x4 &a = st[mt][0], &b = st[mt][1];
+        const float tmax = rowgroup_max(fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])),
+                                              fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]))));
+        const float m_new = fmaxf(m_run[mt], tmax * scale_log2);
+        // a row with nothing visible yet keeps m = -inf; exponents are then taken against 0 (all scores are -inf)
+        m_use[mt] = m_new == -INFINITY ? 0.0f : m_new;
+        alpha[mt] = __builtin_amdgcn_exp2f(m_run[mt] - m_use[mt]);
+        m_run[mt] = m_new;
+      }
+      bf16x8 pfrag[NT], pfrag_lo[NT];
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt) {
+        float pv[8], psum = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[mt][e >> 2][e & 3], scale_log2, -m_use[mt]));
+          psum += pv[e];
+        }
+        l_run[mt] = l_run[mt] * alpha[mt] + psum;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          pfrag[mt][e] = static_cast<__bf16>(pv[e]);
+          pfrag_lo[mt][e] = static_cast<__bf16>(pv[e] - static_cast<float>(pfrag[mt][e]));
+        }
+      }
+      bool steady = true;  // no row maximum moved in this tile (the common case after the first few tiles)
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt) steady = steady && alpha[mt] == 1.0f;
+      if (!__all(steady)) {
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+          for (int dt = 0; dt < 8; ++dt) o_acc[mt][dt] *= alpha[mt];
+      }
       const int q4 = c16 >> 2, p4 = c16 & 3;
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt) {
@@ -688,14 +832,26 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         const bf16x8 vfrag = __builtin_bit_cast(bf16x8, both);
 #pragma unroll
-        for (int mt = 0; mt < RT; ++mt) {
+        for (int mt = 0; mt < NT; ++mt) {
           o_acc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pfrag[mt], o_acc[mt][dt], 0, 0, 0);
           o_acc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pfrag_lo[mt], o_acc[mt][dt], 0, 0, 0);
         }
       }
     }
+  };
+  if (my_tiles >= 3) {
+    tile_loop(std::integral_constant<int, 3>{});
+  } else if (my_tiles == 2) {
+    tile_loop(std::integral_constant<int, 2>{});
+  } else if (my_tiles == 1) {
+    tile_loop(std::integral_constant<int, 1>{});
+  } else {
+    for (int it = 0; it < n_iter; ++it) __syncthreads();  // an idle wave still meets the loaders' barriers
   }
 
+  float l_tot[RT];  // the per-lane partial row sums of the four token groups, combined (all lanes take part)
+#pragma unroll
+  for (int mt = 0; mt < RT; ++mt) l_tot[mt] = rowgroup_sum(l_run[mt]);
 #pragma unroll
   for (int mt = 0; mt < RT; ++mt) {
     if (!row_ok[mt]) continue;
@@ -711,7 +867,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (g == 0) {
       float* mp = P.ws_ml + (static_cast<int64_t>(blockIdx.y) * P.total_rows + grow) * 2;
       mp[0] = m_run[mt] * kLn2;
-      mp[1] = l_run[mt];
+      mp[1] = l_tot[mt];
       if (blockIdx.y == 0) mark_unused_parts(P, grow);
     }
   }
@@ -874,6 +1030,7 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   P.req_list = nullptr;
   P.k_scale = k_scale;
   P.v_scale = v_scale;
+  P.dbg = []() { const char* e = getenv("AIC_ATTN_DBG"); return e ? atoi(e) : 0; }();
 
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;

@@ -89,6 +89,11 @@ if __name__ == "__main__":
         attn(B=16, qlen=33, split=True)
         attn(B=4, qlen=33, split=True)
         attn(B=1, qlen=33, split=True)
+    if "long" in what:
+        attn(B=16, qlen=33, split=True)
+        attn(B=16, qlen=17, split=True)
+        attn(B=5, qlen=33, split=True)
+        attn(B=1, qlen=33, split=True)
     if "lstm" in what:
         lstm(64)
         lstm(32)
