@@ -880,21 +880,43 @@ verify_attn_combine_kernel(const float* __restrict__ ws_o, const float* __restri
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= total_rows) return;
-  float M = -INFINITY;
-  for (int p = lane; p < n_parts; p += 64) M = fmaxf(M, ws_ml[(static_cast<int64_t>(p) * total_rows + row) * 2]);
+  // lane p holds slot p's {max, sum} (n_parts <= 64): the weights of all slots come from one load and two wave
+  // reductions, and the loop below only issues independent loads (a weight read inside the loop made every
+  // slot's load wait for the previous one)
+  float m_l = -INFINITY, l_l = 0.0f;
+  if (lane < n_parts) {
+    const float2 ml = *reinterpret_cast<const float2*>(ws_ml + (static_cast<int64_t>(lane) * total_rows + row) * 2);
+    m_l = ml.x;
+    l_l = ml.y;
+  }
+  float M = m_l;
   for (int off = 32; off > 0; off >>= 1) M = fmaxf(M, __shfl_xor(M, off));
-  float acc0 = 0.0f, acc1 = 0.0f, L = 0.0f;
-  for (int p = 0; p < n_parts; ++p) {
-    const float* ml = ws_ml + (static_cast<int64_t>(p) * total_rows + row) * 2;
-    const float mp = ml[0];
-    if (mp == -INFINITY) continue;
-    const float w = __expf(mp - M);
-    L += w * ml[1];
-    const float2 o = *reinterpret_cast<const float2*>(ws_o + (static_cast<int64_t>(p) * total_rows + row) * kD + 2 * lane);
-    acc0 += w * o.x;
-    acc1 += w * o.y;
+  const float w_l = m_l == -INFINITY ? 0.0f : __expf(m_l - M);
+  float L = w_l * l_l;
+  for (int off = 32; off > 0; off >>= 1) L += __shfl_xor(L, off);
+  // empty slots (weight 0: never written, may hold anything) are redirected to a live slot so that the loads
+  // stay unconditional and independent of each other; their weight of 0 drops the value
+  const unsigned long long live = __ballot(w_l != 0.0f);
+  const int p_ok = live ? __ffsll(live) - 1 : 0;
+  float acc0 = 0.0f, acc1 = 0.0f;
+  for (int p0 = 0; p0 < n_parts; p0 += 4) {
+    float w[4];
+    float2 o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int pj = p0 + j;
+      w[j] = pj < n_parts ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w_l), pj & 63)) : 0.0f;
+      const int pe = w[j] != 0.0f ? pj : p_ok;
+      o[j] = *reinterpret_cast<const float2*>(ws_o + (static_cast<int64_t>(pe) * total_rows + row) * kD + 2 * lane);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc0 += w[j] * o[j].x;
+      acc1 += w[j] * o[j].y;
+    }
   }
   const float inv = L > 0.0f ? 1.0f / L : 0.0f;
+  if (!(L > 0.0f)) acc0 = acc1 = 0.0f;  // a row with nothing visible (cannot happen for a real token): zeros
   const int tok = row / num_q_heads, head = row - tok * num_q_heads;
   uint16_t* op = out + static_cast<int64_t>(tok) * out_stride + static_cast<int64_t>(head) * kD + 2 * lane;
   const uint32_t packed = static_cast<uint32_t>(f32_to_bf16(acc0 * inv)) | (static_cast<uint32_t>(f32_to_bf16(acc1 * inv)) << 16);
