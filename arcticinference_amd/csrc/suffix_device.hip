@@ -790,6 +790,20 @@ int aic_sc_update_response(aic_suffix_cache* c, int64_t req, const int32_t* toke
   return AIC_OK;
 }
 
+int aic_sc_update_responses(aic_suffix_cache* c, int n_req, const int64_t* reqs, const int32_t* tokens,
+                            const int32_t* lens) {
+  AIC_REQUIRE(c && n_req >= 0 && (n_req == 0 || (reqs && lens)), "bad arguments to aic_sc_update_responses");
+  int64_t at = 0;
+  for (int r = 0; r < n_req; ++r) {
+    AIC_REQUIRE(lens[r] >= 0 && (tokens || lens[r] == 0), "bad token run for request %d", r);
+    // same order as one update_response per request (the global tree sees the requests' tokens in list order)
+    const int rc = aic_sc_update_response(c, reqs[r], tokens + at, lens[r]);
+    if (rc != AIC_OK) return rc;
+    at += lens[r];
+  }
+  return AIC_OK;
+}
+
 int aic_sc_speculate_batch(aic_suffix_cache* c, int n_query, const int64_t* reqs, const int32_t* patterns,
                            const int32_t* pattern_lens, const int32_t* max_spec_tokens, const float* factor,
                            const float* offset, const float* min_prob, const int32_t* use_prompt, int cap,

@@ -577,6 +577,108 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((M
 }
 
 
+// One 32-token KV tile (K and V images in LDS at kb / vb, v_tile_off layout) against the NT row tiles of a wave
+// of the long-draft kernels: all NT x 8 score MFMAs first, then a branch-free soft-max over the NT tiles (the
+// scale folded into the exponent's fma, row maxima by VALU lane swaps, row sums kept as per-lane partials), then
+// the PV MFMAs.  Straight-line code: with one soft-max call per row tile the calls' branches kept the MFMA
+// chains and the VALU work of different row tiles from overlapping, and the wave (alone on its SIMD) ran at the
+// sum of every latency.
+template <int NT, int RT>
+__device__ __forceinline__ void long_tile_compute(const char* kb, const char* vb, const uint4 (&qf)[RT][4],
+                                                  const bool (&row_ok)[RT], const int (&row_pos)[RT],
+                                                  float (&m_run)[RT], float (&l_run)[RT], f32x4 (&o_acc)[RT][8], int tt,
+                                                  int t_end, int ctx, int q_len, float scale_log2, int g, int c16) {
+    // K fragments of the tile (A operand of S^T = K Q^T): lane (token c16 [+16], d = 32 s + 8 g)
+    uint4 kf[2][4];
+#pragma unroll
+    for (int th = 0; th < 2; ++th)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kf[th][s] = *reinterpret_cast<const uint4*>(kb + v_tile_off(16 * th + c16, 4 * s + g));
+
+    f32x4 st[NT][2];
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+      for (int th = 0; th < 2; ++th) st[mt][th] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int th = 0; th < 2; ++th)
+          st[mt][th] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[th][s]),
+                                                               __builtin_bit_cast(bf16x8, qf[mt][s]), st[mt][th], 0, 0, 0);
+    const bool need_mask = tt + kTile > t_end || tt + kTile > ctx - q_len + 1;
+    if (need_mask) {
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt) {
+        const int limit = ctx - q_len + row_pos[mt];
+#pragma unroll
+        for (int th = 0; th < 2; ++th)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int tok = tt + 16 * th + 4 * g + e;
+            if (!(row_ok[mt] && tok < t_end && tok <= limit)) st[mt][th][e] = -INFINITY;
+          }
+      }
+    }
+    float alpha[NT], m_use[NT];
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+      const f32x4 &a = st[mt][0], &b = st[mt][1];
+      const float tmax = rowgroup_max(fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])),
+                                            fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]))));
+      const float m_new = fmaxf(m_run[mt], tmax * scale_log2);
+      // a row with nothing visible yet keeps m = -inf; exponents are then taken against 0 (all scores are -inf)
+      m_use[mt] = m_new == -INFINITY ? 0.0f : m_new;
+      alpha[mt] = __builtin_amdgcn_exp2f(m_run[mt] - m_use[mt]);
+      m_run[mt] = m_new;
+    }
+    bf16x8 pfrag[NT], pfrag_lo[NT];
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+      float pv[8], psum = 0.0f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[mt][e >> 2][e & 3], scale_log2, -m_use[mt]));
+        psum += pv[e];
+      }
+      l_run[mt] = l_run[mt] * alpha[mt] + psum;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        pfrag[mt][e] = static_cast<__bf16>(pv[e]);
+        pfrag_lo[mt][e] = static_cast<__bf16>(pv[e] - static_cast<float>(pfrag[mt][e]));
+      }
+    }
+    bool steady = true;  // no row maximum moved in this tile (the common case after the first few tiles)
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) steady = steady && alpha[mt] == 1.0f;
+    if (!__all(steady)) {
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) o_acc[mt][dt] *= alpha[mt];
+    }
+    const int q4 = c16 >> 2, p4 = c16 & 3;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      const char* a_lo = vb + v_tile_off(4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
+      const char* a_hi = vb + v_tile_off(16 + 4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(a_lo)));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(a_hi)));
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+      const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      const bf16x8 vfrag = __builtin_bit_cast(bf16x8, both);
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt) {
+        o_acc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pfrag[mt], o_acc[mt][dt], 0, 0, 0);
+        o_acc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pfrag_lo[mt], o_acc[mt][dt], 0, 0, 0);
+      }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Long-draft variant (suffix drafts: up to 33 query positions = 132 rows at G = 4).  A workgroup is 8 waves on
 // ONE kv head and one token range: waves 0-3 compute, each on its own row tiles (wave w owns row tiles
@@ -746,97 +848,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       const int buf = it & 1;
       __syncthreads();  // buffer `buf` is complete; the loaders may now overwrite buffer buf ^ 1
       if (P.dbg & 2) continue;
-      const char* kb = reinterpret_cast<const char*>(kv_lds[buf][0]);
-      const char* vb = reinterpret_cast<const char*>(kv_lds[buf][1]);
-      // K fragments of the tile (A operand of S^T = K Q^T): lane (token c16 [+16], d = 32 s + 8 g)
-      uint4 kf[2][4];
-#pragma unroll
-      for (int th = 0; th < 2; ++th)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) kf[th][s] = *reinterpret_cast<const uint4*>(kb + v_tile_off(16 * th + c16, 4 * s + g));
-
-      f32x4 st[NT][2];
-#pragma unroll
-      for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-        for (int th = 0; th < 2; ++th) st[mt][th] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-          for (int th = 0; th < 2; ++th)
-            st[mt][th] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[th][s]),
-                                                                 __builtin_bit_cast(bf16x8, qf[mt][s]), st[mt][th], 0, 0, 0);
-      const bool need_mask = tt + kTile > t_end || tt + kTile > ctx - q_len + 1;
-      if (need_mask) {
-#pragma unroll
-        for (int mt = 0; mt < NT; ++mt) {
-          const int limit = ctx - q_len + row_pos[mt];
-#pragma unroll
-          for (int th = 0; th < 2; ++th)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int tok = tt + 16 * th + 4 * g + e;
-              if (!(row_ok[mt] && tok < t_end && tok <= limit)) st[mt][th][e] = -INFINITY;
-            }
-        }
-      }
-      float alpha[NT], m_use[NT];
-#pragma unroll
-      for (int mt = 0; mt < NT; ++mt) {
-        const f32x4 &a = st[mt][0], &b = st[mt][1];
-        const float tmax = rowgroup_max(fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])),
-                                              fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]))));
-        const float m_new = fmaxf(m_run[mt], tmax * scale_log2);
-        // a row with nothing visible yet keeps m = -inf; exponents are then taken against 0 (all scores are -inf)
-        m_use[mt] = m_new == -INFINITY ? 0.0f : m_new;
-        alpha[mt] = __builtin_amdgcn_exp2f(m_run[mt] - m_use[mt]);
-        m_run[mt] = m_new;
-      }
-      bf16x8 pfrag[NT], pfrag_lo[NT];
-#pragma unroll
-      for (int mt = 0; mt < NT; ++mt) {
-        float pv[8], psum = 0.0f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[mt][e >> 2][e & 3], scale_log2, -m_use[mt]));
-          psum += pv[e];
-        }
-        l_run[mt] = l_run[mt] * alpha[mt] + psum;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          pfrag[mt][e] = static_cast<__bf16>(pv[e]);
-          pfrag_lo[mt][e] = static_cast<__bf16>(pv[e] - static_cast<float>(pfrag[mt][e]));
-        }
-      }
-      bool steady = true;  // no row maximum moved in this tile (the common case after the first few tiles)
-#pragma unroll
-      for (int mt = 0; mt < NT; ++mt) steady = steady && alpha[mt] == 1.0f;
-      if (!__all(steady)) {
-#pragma unroll
-        for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-          for (int dt = 0; dt < 8; ++dt) o_acc[mt][dt] *= alpha[mt];
-      }
-      const int q4 = c16 >> 2, p4 = c16 & 3;
-#pragma unroll
-      for (int dt = 0; dt < 8; ++dt) {
-        const char* a_lo = vb + v_tile_off(4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
-        const char* a_hi = vb + v_tile_off(16 + 4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(a_lo)));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(a_hi)));
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
-        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        const bf16x8 vfrag = __builtin_bit_cast(bf16x8, both);
-#pragma unroll
-        for (int mt = 0; mt < NT; ++mt) {
-          o_acc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pfrag[mt], o_acc[mt][dt], 0, 0, 0);
-          o_acc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pfrag_lo[mt], o_acc[mt][dt], 0, 0, 0);
-        }
-      }
+      long_tile_compute<NT, RT>(reinterpret_cast<const char*>(kv_lds[buf][0]), reinterpret_cast<const char*>(kv_lds[buf][1]),
+                                qf, row_ok, row_pos, m_run, l_run, o_acc, tt, t_end, ctx, q_len, scale_log2, g, c16);
     }
   };
   if (my_tiles >= 3) {
@@ -864,6 +877,179 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       *reinterpret_cast<float4*>(op + dt * 16) =
           make_float4(o_acc[mt][dt][0] * out_scale, o_acc[mt][dt][1] * out_scale, o_acc[mt][dt][2] * out_scale,
                       o_acc[mt][dt][3] * out_scale);
+    if (g == 0) {
+      float* mp = P.ws_ml + (static_cast<int64_t>(blockIdx.y) * P.total_rows + grow) * 2;
+      mp[0] = m_run[mt] * kLn2;
+      mp[1] = l_tot[mt];
+      if (blockIdx.y == 0) mark_unused_parts(P, grow);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Long-draft kernel for a bf16 cache, co-resident form.  Same work split as verify_attn_long_kernel (one kv
+// head and one token range per workgroup, wave w owns row tiles w, w+4, w+8, KV bytes read once for up to 192
+// rows) but FOUR waves and no loader waves: every VGPR allocation of a kernel is uniform, so the four loader
+// waves above held half of a CU's register file for nothing and a workgroup needed a whole empty CU -- beside
+// the short-request kernel (one 4-wave workgroup per CU) it could only start when that kernel drained, and the
+// "overlapped" pair ran back to back.  Here each wave moves its quarter of every K/V tile with LDS-DMA
+// (global_load_lds_dwordx4: no VGPR destination, 1 KiB per wave-instruction) into a ring of four 16 KiB tile
+// images, three tiles in flight, counted vmcnt + one raw s_barrier per tile; at <= 256 VGPRs and 64 KiB of LDS
+// a workgroup fits beside a short-request workgroup on the same CU and its MFMA / VALU work fills that
+// kernel's memory stalls.  The LDS image is the v_tile_off layout: the DMA writes lane-linear, so the row
+// permutation and chunk swizzle are applied on the per-lane SOURCE address (cdna guide rule 21).
+// The loads are inline asm: hipcc does not count them, the s_waitcnt below are the only vmcnt waits in the
+// loop (the Q loads are drained before the first DMA is issued).
+// ------------------------------------------------------------------------------------------------------
+constexpr int kLongRing = 4;   // LDS tile images
+constexpr int kLongAhead = 3;  // tiles in flight
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) verify_attn_long4_kernel(AttnParams P) {
+  constexpr int RT = kLongTilesPerWave;
+  __shared__ uint4 kv_lds[kLongRing][2][kTile * 16];  // [ring slot][K|V][32 tokens x 16 chunks]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c16 = lane & 15;
+  const int Hkv = P.num_kv_heads, Hq = P.num_q_heads, G = Hq / Hkv;
+  const int ridx = blockIdx.x / Hkv;
+  const int h = blockIdx.x - ridx * Hkv;
+  const int req = __builtin_amdgcn_readfirstlane(P.req_list ? P.req_list[ridx] : ridx);
+  const int q0 = __builtin_amdgcn_readfirstlane(P.query_start_loc[req]);
+  const int q_len = __builtin_amdgcn_readfirstlane(P.query_start_loc[req + 1]) - q0;
+  const int ctx = __builtin_amdgcn_readfirstlane(P.seq_lens[req]);
+  const int n_rows = q_len * G;
+  const int row_base = blockIdx.z * (4 * RT * 16);
+  if (row_base >= n_rows) return;
+
+  const int tiles_total = (ctx + kTile - 1) / kTile;
+  const int tiles_per_part = (tiles_total + P.n_splits - 1) / P.n_splits;
+  const int t_begin = blockIdx.y * tiles_per_part * kTile;
+  const int t_end = min(ctx, t_begin + tiles_per_part * kTile);
+  const int n_iter = t_begin < t_end ? (t_end - t_begin + kTile - 1) / kTile : 0;
+
+  const int64_t kv_row = static_cast<int64_t>(Hkv) * kD;
+  const_i32_ptr btab = (const_i32_ptr)(P.block_table + static_cast<int64_t>(req) * P.max_blocks);
+  const int bs = P.block_size;
+  const int last_group = (ctx - 1) & ~15;
+
+  // ---- query rows of this wave ----
+  const float scale_log2 = P.sm_scale * kLog2e;
+  uint4 qf[RT][4];
+  int row_pos[RT];
+  bool row_ok[RT];
+#pragma unroll
+  for (int mt = 0; mt < RT; ++mt) {
+    const int rr = row_base + (wave + 4 * mt) * 16 + c16;
+    row_ok[mt] = rr < n_rows;
+    const int rc = min(rr, n_rows - 1);
+    const int pos = rc / G, gq = rc - pos * G;
+    row_pos[mt] = pos;
+    const uint16_t* qp = P.q + static_cast<int64_t>(q0 + pos) * P.q_stride + static_cast<int64_t>(h * G + gq) * kD + 8 * g;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[mt][s] = *reinterpret_cast<const uint4*>(qp + 32 * s);
+  }
+  // the Q loads are the only compiler-counted vector loads: retire them before any DMA is in flight, otherwise
+  // hipcc's wait for them (vmcnt(0), placed at their first use INSIDE the loop) would drain the ring every tile
+#pragma unroll
+  for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      asm volatile("" : "+v"(qf[mt][s].x), "+v"(qf[mt][s].y), "+v"(qf[mt][s].z), "+v"(qf[mt][s].w));
+
+  float m_run[RT], l_run[RT];
+  f32x4 o_acc[RT][8];
+#pragma unroll
+  for (int mt = 0; mt < RT; ++mt) {
+    m_run[mt] = -INFINITY;
+    l_run[mt] = 0.0f;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) o_acc[mt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int n_row_tiles = (min(n_rows - row_base, 4 * RT * 16) + 15) >> 4;
+  const int my_tiles = __builtin_amdgcn_readfirstlane(n_row_tiles > wave ? (n_row_tiles - wave + 3) >> 2 : 0);
+
+  // ---- this wave's share of a tile: LDS rows 4 w .. 4 w + 3 and 16 + 4 w .. (1 KiB each) of K and of V ----
+  // LDS slot (row r, chunk slot c) holds chunk c ^ f(r) of token swap23(r)  (the inverse of v_tile_off)
+  const int r0 = 4 * wave + g;                                             // < 16: first page of the tile
+  const int tk = (r0 & ~12) | ((r0 & 4) << 1) | ((r0 & 8) >> 1);          // token of that row; row r0 + 16 -> tk + 16
+  const int ch = c16 ^ (((r0 & 3) << 2) | ((r0 >> 2) & 3));               // same for both rows
+  const char* kc = reinterpret_cast<const char*>(P.k_cache);
+  const char* vc = reinterpret_cast<const char*>(P.v_cache);
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<size_t>(
+      (__attribute__((address_space(3))) void*)(&kv_lds[0][0][0])));
+  auto issue = [&](int jt) {
+    const int tt = t_begin + jt * kTile;
+    const int f0 = min(tt, last_group), f1 = min(tt + 16, last_group);
+    const int64_t b0 = static_cast<int64_t>(btab[f0 / bs]) * P.block_stride + static_cast<int64_t>(f0 % bs) * kv_row + h * kD;
+    const int64_t b1 = static_cast<int64_t>(btab[f1 / bs]) * P.block_stride + static_cast<int64_t>(f1 % bs) * kv_row + h * kD;
+    const int64_t o0 = 2 * (b0 + static_cast<int64_t>(min(tt + tk, ctx - 1) - f0) * kv_row + 8 * ch);
+    const int64_t o1 = 2 * (b1 + static_cast<int64_t>(min(tt + 16 + tk, ctx - 1) - f1) * kv_row + 8 * ch);
+    const unsigned slot = lds0 + static_cast<unsigned>(jt & (kLongRing - 1)) * (2 * kTile * 256) + 1024 * wave;
+    glds16(kc + o0, slot);
+    glds16(kc + o1, slot + 4096);
+    glds16(vc + o0, slot + kTile * 256);
+    glds16(vc + o1, slot + kTile * 256 + 4096);
+  };
+#pragma unroll
+  for (int d = 0; d < kLongAhead; ++d)
+    if (d < n_iter) issue(d);
+
+  auto tile_loop = [&](auto nt_tag) {
+    constexpr int NT = decltype(nt_tag)::value;
+    for (int it = 0; it < n_iter; ++it) {
+      // tile `it` has landed when at most the tiles issued after it (4 DMAs each) are still outstanding
+      const int rem = n_iter - 1 - it;
+      if (rem >= 2) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else if (rem == 1) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();  // every wave's quarter of tile `it` is in LDS; ring slot (it - 1) & 3 is free
+      asm volatile("" ::: "memory");
+      if (it + kLongAhead < n_iter) issue(it + kLongAhead);
+      if constexpr (NT > 0) {
+        const int slot = it & (kLongRing - 1);
+        long_tile_compute<NT, RT>(reinterpret_cast<const char*>(kv_lds[slot][0]), reinterpret_cast<const char*>(kv_lds[slot][1]),
+                                  qf, row_ok, row_pos, m_run, l_run, o_acc, t_begin + it * kTile, t_end, ctx, q_len,
+                                  scale_log2, g, c16);
+      }
+    }
+  };
+  if (my_tiles >= 3) {
+    tile_loop(std::integral_constant<int, 3>{});
+  } else if (my_tiles == 2) {
+    tile_loop(std::integral_constant<int, 2>{});
+  } else if (my_tiles == 1) {
+    tile_loop(std::integral_constant<int, 1>{});
+  } else {
+    tile_loop(std::integral_constant<int, 0>{});  // no rows of its own: the wave still moves its quarter of the tiles
+  }
+
+  float l_tot[RT];
+#pragma unroll
+  for (int mt = 0; mt < RT; ++mt) l_tot[mt] = rowgroup_sum(l_run[mt]);
+#pragma unroll
+  for (int mt = 0; mt < RT; ++mt) {
+    if (!row_ok[mt]) continue;
+    const int rr = row_base + (wave + 4 * mt) * 16 + c16;
+    const int pos = rr / G, gq = rr - pos * G;
+    const int64_t grow = static_cast<int64_t>(q0 + pos) * Hq + h * G + gq;
+    float* op = P.ws_o + (static_cast<int64_t>(blockIdx.y) * P.total_rows + grow) * kD + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+      *reinterpret_cast<float4*>(op + dt * 16) =
+          make_float4(o_acc[mt][dt][0], o_acc[mt][dt][1], o_acc[mt][dt][2], o_acc[mt][dt][3]);
     if (g == 0) {
       float* mp = P.ws_ml + (static_cast<int64_t>(blockIdx.y) * P.total_rows + grow) * 2;
       mp[0] = m_run[mt] * kLn2;
@@ -1101,8 +1287,10 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
       dim3 grid(static_cast<unsigned>(n_long * num_kv_heads), n_splits_long, (max_rows + per_block_rows - 1) / per_block_rows);
       if (kv8)
         hipLaunchKernelGGL(verify_attn_long_kernel<true>, grid, dim3(512), 0, overlap ? side->stream : s, PL);
-      else
+      else if (P.dbg & 4)
         hipLaunchKernelGGL(verify_attn_long_kernel<false>, grid, dim3(512), 0, overlap ? side->stream : s, PL);
+      else
+        hipLaunchKernelGGL(verify_attn_long4_kernel, grid, dim3(256), 0, overlap ? side->stream : s, PL);
       if (overlap) AIC_HIP_TRY(hipEventRecord(side->join, side->stream));
       return AIC_OK;
     };

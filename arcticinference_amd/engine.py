@@ -119,7 +119,10 @@ class HotPathEngine:
         self.attn_out = torch.empty(tq, self.hq_local * s.head_size, dtype=torch.bfloat16, device=self.device)
         perm = torch.randperm(nb, generator=torch.Generator().manual_seed(seed)).numpy().astype(np.int32)
         self._free_blocks = [perm[i * self.blocks_per_seq:(i + 1) * self.blocks_per_seq] for i in range(max_num_seqs)]
+        self._bt_host = np.stack(self._free_blocks)       # [max_num_seqs, blocks_per_seq]: a slot's pages never change
         self.requests: List[Optional[RequestState]] = [None] * max_num_seqs
+        # vLLM's input_batch.token_ids_cpu: prompt + sampled tokens per slot (the suffix patterns are slices of it)
+        self.token_ids_cpu = np.zeros((max_num_seqs, max_model_len + MAX_SPEC_LEN + 2), dtype=np.int32)
         self.block_table = torch.zeros(max_num_seqs, self.blocks_per_seq, dtype=torch.int32, device=self.device)
         self.sm_scale = s.head_size ** -0.5
         self._plant_col = torch.full((self.max_tokens, 1), 30.0, dtype=torch.bfloat16, device=self.device)
@@ -142,6 +145,7 @@ class HotPathEngine:
             self.suffix_cache.cache_prompt(req_id, r.tokens[:r.num_prompt])
             self.suffix_cache.update_response(req_id, [int(first_token)])
         r.tokens.append(int(first_token))
+        self.token_ids_cpu[slot, :len(r.tokens)] = r.tokens
 
     def add_requests(self, slots, req_ids, prompts, first_tokens, n_threads: int = 8) -> None:
         if self.suffix_cache is not None:
@@ -157,6 +161,7 @@ class HotPathEngine:
             if self.suffix_cache is not None:
                 self.suffix_cache.update_response(rid, [int(ft)])
             r.tokens.append(int(ft))
+            self.token_ids_cpu[s, :len(r.tokens)] = r.tokens
 
     # -- one engine step --------------------------------------------------------------------------------
     def step(self, next_truth) -> List[List[int]]:
@@ -195,7 +200,7 @@ class HotPathEngine:
         bonus_rows = qsl[1:] - 1
 
         # one pinned staging buffer and ONE host->device copy for all of the step's small index arrays
-        slot_map = self._slot_mapping(reqs, q_len, qsl, T)
+        slot_map = self._slot_mapping(live, reqs, q_len, qsl, T)
         parts = [ctx, qsl, draft_flat, np.cumsum(n_draft), plant_tok, target_rows, bonus_rows, np.asarray(live), slot_map]
         kinds = [np.int32, np.int32, np.int32, np.int32, np.int64, np.int64, np.int64, np.int64, np.int64]
         offs, nbytes = [], 0
@@ -256,28 +261,38 @@ class HotPathEngine:
         _mark('wait_gpu_accept')
 
         # (e) host: parse, commit, update the suffix trees while the LSTM kernels run
+        valid = (out_host != -1) & (out_host < s.vocab_size)                  # parse_output (:456-459)
+        n_emit = valid.sum(axis=1).astype(np.int32)
+        flat_emit = out_host[valid]                                            # row-major: request by request
         emitted: List[List[int]] = []
+        at = 0
+        live_arr = np.asarray(live)
         for i, r in enumerate(reqs):
-            row = out_host[i]
-            toks = [int(t) for t in row if t != -1 and t < s.vocab_size]   # parse_output (:456-459)
+            k = int(n_emit[i])
+            toks = flat_emit[at:at + k].tolist()
+            at += k
             emitted.append(toks)
-            self.stats.emitted += len(toks)
-            if n_draft[i]:
-                self.stats.num_drafts += 1
-                self.stats.drafted += int(n_draft[i])
-                self.stats.accepted += len(toks) - 1
+            self.token_ids_cpu[live[i], len(r.tokens):len(r.tokens) + k] = toks
             r.tokens.extend(toks)
             r.drafts = []
+        self.stats.emitted += int(n_emit.sum())
+        had = n_draft > 0
+        self.stats.num_drafts += int(had.sum())
+        self.stats.drafted += int(n_draft.sum())
+        self.stats.accepted += int((n_emit[had] - 1).sum())
         if B > spec.disable_by_batch_size:
             return emitted
         _mark('host_parse')
-        suffix_res: Optional[List[SuffixSpecResult]] = None
+        suffix = None
         if self.suffix_cache is not None:
-            for r, toks in zip(reqs, emitted):
-                if toks:
-                    self.suffix_cache.update_response(r.req_id, toks)          # _update_suffix_cache (:657-678)
+            self.suffix_cache.update_responses([r.req_id for r in reqs], flat_emit, n_emit)   # _update_suffix_cache (:657-678)
             _mark('host_suffix_update')
-            suffix_res = self._propose_suffix(reqs, emitted)
+            # the tree mirror update + match kernels need nothing from the main stream (their input is the host
+            # tree): on a side stream they run beside the LSTM draft instead of queueing behind it
+            if not hasattr(self, "_suffix_stream"):
+                self._suffix_stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(self._suffix_stream):
+                suffix = self._propose_suffix(live_arr, reqs, n_emit)
             _mark('suffix_speculate_roundtrip')
         # (f) merge (:555-566, :595-601)
         lstm_host = lstm_out.cpu().numpy() if lstm_out is not None else None
@@ -286,54 +301,60 @@ class HotPathEngine:
         for i, r in enumerate(reqs):
             room = self.max_model_len - len(r.tokens) - 1
             drafts: List[int] = []
-            if suffix_res is not None and suffix_res[i].score >= min_score and suffix_res[i].token_ids:
-                drafts = list(suffix_res[i].token_ids)
+            if suffix is not None and suffix[1][i] > 0 and suffix[2][i] >= min_score:
+                drafts = suffix[0][i, :suffix[1][i]].tolist()
                 self.stats.suffix_used += 1
-            elif lstm_host is not None and emitted[i]:
+            elif lstm_host is not None and n_emit[i]:
                 k = min(spec.num_speculative_tokens, room)
-                drafts = [int(t) for t in lstm_host[i, :max(k, 0)]]
+                drafts = lstm_host[i, :max(k, 0)].tolist()
             r.drafts = drafts[:max(room, 0)]
         _mark('host_merge')
         return emitted
 
     # -- pieces -------------------------------------------------------------------------------------------
-    def _propose_suffix(self, reqs, emitted) -> List[SuffixSpecResult]:
-        """propose_suffix_draft_token_ids (model_runner.py:680-744) for the whole batch at once."""
+    def _propose_suffix(self, live_arr, reqs, n_emit):
+        """propose_suffix_draft_token_ids (model_runner.py:680-744) for the whole batch at once, on arrays.
+        Returns (tokens [B, cap], n_tokens [B], score [B]); requests that are skipped keep n_tokens = 0."""
         cfg = self.spec
-        ids, pats, mst, fac, off, mpr = [], [], [], [], [], []
-        where = []
-        out = [SuffixSpecResult() for _ in reqs]
-        for i, (r, toks) in enumerate(zip(reqs, emitted)):
-            if not toks:
-                continue
-            end_idx = len(r.tokens)
-            if end_idx >= self.max_model_len:
-                continue
-            size = min(end_idx, cfg.suffix_cache_max_depth)
-            pattern = r.tokens[end_idx - size:end_idx]
-            m = min(MAX_SPEC_LEN, cfg.suffix_cache_max_depth, self.max_model_len - end_idx - 1)
-            ids.append(r.req_id)
-            pats.append(pattern)
-            mst.append(m)
-            fac.append(cfg.suffix_max_spec_factor)
-            off.append(cfg.suffix_max_spec_offset)
-            mpr.append(cfg.suffix_min_token_prob)
-            where.append(i)
-        if ids:
-            res = self.suffix_cache.speculate_batch(ids, pats, mst, fac, off, mpr, [True] * len(ids))
-            for i, x in zip(where, res):
-                out[i] = x
-            self.last_suffix_stats = self.suffix_cache.last_stats()
-        return out
+        B = len(reqs)
+        end = np.fromiter((len(r.tokens) for r in reqs), dtype=np.int64, count=B)
+        depth = cfg.suffix_cache_max_depth
+        ask = (n_emit > 0) & (end < self.max_model_len)
+        where = np.nonzero(ask)[0]
+        n_tok = np.zeros(B, np.int32)
+        score = np.zeros(B, np.float32)
+        toks = np.zeros((B, 1), np.int32)
+        if len(where) == 0:
+            return toks, n_tok, score
+        e = end[where]
+        size = np.minimum(e, depth)
+        rows = live_arr[where]
+        if int(size.min()) == depth:      # the usual case: every pattern is the full last `depth` tokens
+            idx = (e - depth)[:, None] + np.arange(depth)[None, :]
+            flat = self.token_ids_cpu[rows[:, None], idx].reshape(-1)
+        else:
+            flat = np.concatenate([self.token_ids_cpu[rw, x - z:x] for rw, x, z in zip(rows, e, size)])
+        mst = np.minimum(min(MAX_SPEC_LEN, depth), self.max_model_len - e - 1).astype(np.int32)
+        nq = len(where)
+        o_tok, _, o_n, o_sc, _ = self.suffix_cache.speculate_batch_arrays(
+            [reqs[i].req_id for i in where], flat, size.astype(np.int32), mst,
+            np.full(nq, cfg.suffix_max_spec_factor, np.float32), np.full(nq, cfg.suffix_max_spec_offset, np.float32),
+            np.full(nq, cfg.suffix_min_token_prob, np.float32), np.ones(nq, np.int32))
+        toks = np.zeros((B, o_tok.shape[1]), np.int32)
+        toks[where] = o_tok
+        n_tok[where] = o_n
+        score[where] = o_sc
+        self.last_suffix_stats = self.suffix_cache.last_stats()
+        return toks, n_tok, score
 
-    def _slot_mapping(self, reqs, q_len, qsl, T) -> np.ndarray:
-        s = self.shape
-        slot_map = np.empty(T, dtype=np.int64)
-        for i, r in enumerate(reqs):
-            first = len(r.tokens) - 1            # position of the last sampled token (not in the cache yet)
-            pos = first + np.arange(q_len[i])
-            slot_map[qsl[i]:qsl[i + 1]] = r.blocks[pos // s.block_size].astype(np.int64) * s.block_size + pos % s.block_size
-        return slot_map
+    def _slot_mapping(self, live, reqs, q_len, qsl, T) -> np.ndarray:
+        """KV slot of every token of the step (one vectorised pass: row i covers positions first_i .. first_i + q_len_i - 1,
+        first_i = position of the last sampled token, which is not in the cache yet)."""
+        bs = self.shape.block_size
+        first = np.fromiter((len(r.tokens) - 1 for r in reqs), dtype=np.int64, count=len(reqs))
+        rep = np.repeat(np.arange(len(reqs)), q_len)
+        pos = first[rep] + (np.arange(T) - qsl[:-1][rep])
+        return self._bt_host[np.asarray(live)[rep], pos // bs].astype(np.int64) * bs + pos % bs
 
     def _write_kv(self, d_slots, T) -> None:
         s = self.shape

@@ -183,6 +183,16 @@ class SuffixCache:
         a = _i32([token_ids] if isinstance(token_ids, (int, np.integer)) else token_ids)
         N.check(N.lib().aic_sc_update_response(self._h, self._key(req_id), a.ctypes.data, a.size))
 
+    def update_responses(self, req_ids: Sequence[Hashable], flat_tokens: np.ndarray, lens: np.ndarray):
+        """update_response for several requests in one native call: request i appends lens[i] tokens of the
+        concatenated int32 array (the per-request loop of model_runner.py:657-678)."""
+        keys = np.asarray([self._key(r) for r in req_ids], np.int64)
+        flat = np.ascontiguousarray(flat_tokens, dtype=np.int32)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        if len(keys) != len(lens) or int(lens.sum()) != flat.size:
+            raise ValueError("update_responses: lens do not add up to the token array")
+        N.check(N.lib().aic_sc_update_responses(self._h, len(keys), keys.ctypes.data, flat.ctypes.data, lens.ctypes.data))
+
     def speculate(self, req_id: Hashable, pattern: Sequence[int], max_spec_tokens: Optional[int] = None,
                   max_spec_factor: float = 1.0, max_spec_offset: float = 0.0, min_token_prob: float = 0.1,
                   use_tree_spec: bool = False, use_cached_prompt: bool = True) -> SuffixSpecResult:
@@ -218,36 +228,51 @@ class SuffixCache:
         n = len(req_ids)
         if n == 0:
             return []
-        for r, p, up in zip(req_ids, patterns, use_cached_prompt):
-            if up and r not in self._prompt_ids:
-                raise ValueError(f"Prompt does not exist for request '{r}'")
+        for p in patterns:
             if len(p) == 0:
                 raise ValueError("Pattern must not be empty")
         arrs = [_i32(p)[-self._max_depth:] for p in patterns]
-        flat = np.concatenate(arrs)
-        lens = np.asarray([a.size for a in arrs], np.int32)
-        keys = np.asarray([self._key(r) for r in req_ids], np.int64)
-        mst = np.asarray(max_spec_tokens, np.int32)
-        fac = np.asarray(max_spec_factor, np.float32)
-        off = np.asarray(max_spec_offset, np.float32)
-        mpr = np.asarray(min_token_prob, np.float32)
-        upr = np.asarray([1 if u else 0 for u in use_cached_prompt], np.int32)
-        cap = max(1, min(int(mst.max()), self._max_depth))
-        o_tok = np.zeros((n, cap), np.int32)
-        o_prb = np.zeros((n, cap), np.float32)
-        o_n = np.zeros(n, np.int32)
-        o_sc = np.zeros(n, np.float32)
-        o_ml = np.zeros(n, np.int32)
-        N.check(N.lib().aic_sc_speculate_batch(
-            self._h, n, keys.ctypes.data, flat.ctypes.data, lens.ctypes.data, mst.ctypes.data, fac.ctypes.data,
-            off.ctypes.data, mpr.ctypes.data, upr.ctypes.data, cap, o_tok.ctypes.data, o_prb.ctypes.data,
-            o_n.ctypes.data, o_sc.ctypes.data, o_ml.ctypes.data, _stream()))
+        o_tok, o_prb, o_n, o_sc, o_ml = self.speculate_batch_arrays(
+            req_ids, np.concatenate(arrs), np.asarray([a.size for a in arrs], np.int32), max_spec_tokens,
+            max_spec_factor, max_spec_offset, min_token_prob, use_cached_prompt)
         out = []
         for i in range(n):
             k = int(o_n[i])
             out.append(SuffixSpecResult(o_tok[i, :k].tolist(), list(range(-1, k - 1)),
                                         [float(x) for x in o_prb[i, :k]], float(o_sc[i]), int(o_ml[i])))
         return out
+
+    def speculate_batch_arrays(self, req_ids, flat_patterns: np.ndarray, pattern_lens: np.ndarray, max_spec_tokens,
+                               max_spec_factor, max_spec_offset, min_token_prob, use_cached_prompt):
+        """speculate_batch on flat arrays (the engine's per-step form: no per-request Python objects).  Patterns
+        are concatenated int32 (at most max_depth tokens each).  Returns (tokens [n, cap], probs [n, cap],
+        n_tokens [n], score [n], match_len [n]); candidate i is the path tokens[i, :n_tokens[i]]."""
+        n = len(req_ids)
+        for r, up in zip(req_ids, use_cached_prompt):
+            if up and r not in self._prompt_ids:
+                raise ValueError(f"Prompt does not exist for request '{r}'")
+        flat = np.ascontiguousarray(flat_patterns, dtype=np.int32)
+        lens = np.ascontiguousarray(pattern_lens, dtype=np.int32)
+        if n and (int(lens.min()) <= 0 or int(lens.max()) > self._max_depth or int(lens.sum()) != flat.size):
+            raise ValueError("Pattern must not be empty (and at most max_depth tokens, lens adding up)")
+        keys = np.asarray([self._key(r) for r in req_ids], np.int64)
+        mst = np.ascontiguousarray(max_spec_tokens, np.int32)
+        fac = np.ascontiguousarray(max_spec_factor, np.float32)
+        off = np.ascontiguousarray(max_spec_offset, np.float32)
+        mpr = np.ascontiguousarray(min_token_prob, np.float32)
+        upr = np.ascontiguousarray(use_cached_prompt, np.int32)
+        cap = max(1, min(int(mst.max()), self._max_depth)) if n else 1
+        o_tok = np.zeros((n, cap), np.int32)
+        o_prb = np.zeros((n, cap), np.float32)
+        o_n = np.zeros(n, np.int32)
+        o_sc = np.zeros(n, np.float32)
+        o_ml = np.zeros(n, np.int32)
+        if n:
+            N.check(N.lib().aic_sc_speculate_batch(
+                self._h, n, keys.ctypes.data, flat.ctypes.data, lens.ctypes.data, mst.ctypes.data, fac.ctypes.data,
+                off.ctypes.data, mpr.ctypes.data, upr.ctypes.data, cap, o_tok.ctypes.data, o_prb.ctypes.data,
+                o_n.ctypes.data, o_sc.ctypes.data, o_ml.ctypes.data, _stream()))
+        return o_tok, o_prb, o_n, o_sc, o_ml
 
     def last_stats(self) -> dict:
         us = ctypes.c_float(0)

@@ -50,8 +50,8 @@ int aic_version(void);
 /* number of visible HIP devices (0 on a CPU-only box); never initialises a context */
 int aic_device_count(void);
 /* Device timing of the dominant kernel (verify_attn_kernel) for bench.py's roofline figure: while
- * enabled every launch of that kernel is bracketed by a HIP event pair on its own stream;
- * aic_profile_read synchronises them, returns {sum of microseconds, launches} and resets. */
+ * enabled (on = n >= 1) every n-th launch of that kernel is bracketed by a HIP event pair on its own
+ * stream; aic_profile_read synchronises them, returns {sum of microseconds, timed launches} and resets. */
 int aic_profile_enable(int on);
 int aic_profile_read(double* total_us, int* launches);
 
@@ -116,6 +116,10 @@ int aic_sc_cache_prompts(aic_suffix_cache* c, int n_req, const int64_t* reqs, co
 int aic_sc_evict_prompt(aic_suffix_cache* c, int64_t req);
 /* update_response suffix_cache.py:118-149; seq ids are dense in first-seen order (:113-116) */
 int aic_sc_update_response(aic_suffix_cache* c, int64_t req, const int32_t* tokens /*host*/, int n);
+/* the per-request loop of _update_suffix_cache (model_runner.py:657-678) in one call: request r appends
+ * lens[r] tokens of the concatenated host array, in list order (identical to n_req update_response calls) */
+int aic_sc_update_responses(aic_suffix_cache* c, int n_req, const int64_t* reqs, const int32_t* tokens /*host, concatenated*/,
+                            const int32_t* lens);
 
 /* speculate for a batch of requests (suffix_cache.py:151-222 applied per request; the call
  * pattern of model_runner.py:680-744).  All arrays are host arrays of length n_query unless
