@@ -252,12 +252,16 @@ constexpr float kLn2 = 0.6931471805599453f;
 // KV8: the cache holds OCP e4m3 bytes (A16 writes them); tiles are dequantised to bf16 in registers (exact),
 // k_scale folds into the soft-max scale and v_scale into the output, so no per-element scaling is needed.
 // One 16-byte K load then covers the k-slots of TWO MFMA steps, and the Q fragments use the same slot map.
-template <int MTQ, bool WH, bool KV8, int NW = 4>
-__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((MTQ == 1 && NW == 4) ? 3 : 2, (MTQ == 1 && NW == 4) ? 3 : 2))) verify_attn_kernel(AttnParams P) {
+template <int MTQ, int NW>
+struct ShortLds {
   // per wave: one 32-token V tile (8 KiB); reused at the end for the cross-wave merge
-  constexpr int kMergeU4 = (8 * MTQ * 16 + 3 * MTQ * 16 * kD) / 4;
-  constexpr int kLdsU4 = NW * kTile * 16 > kMergeU4 ? NW * kTile * 16 : kMergeU4;
-  __shared__ uint4 v_lds_raw[kLdsU4];
+  static constexpr int kMergeU4 = (8 * MTQ * 16 + 3 * MTQ * 16 * kD) / 4;
+  static constexpr int kU4 = NW * kTile * 16 > kMergeU4 ? NW * kTile * 16 : kMergeU4;
+};
+
+// Body of the short / generic kernel for workgroup (bx, by) of its grid; v_lds_raw = ShortLds<MTQ, NW>::kU4 uint4 of LDS.
+template <int MTQ, bool WH, bool KV8, int NW>
+__device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_lds_raw, const int bx, const int by) {
   uint4(*v_lds)[kTile * 16] = reinterpret_cast<uint4(*)[kTile * 16]>(v_lds_raw);
 
   const int lane = threadIdx.x & 63;
@@ -270,8 +274,8 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((M
   // so the extra row groups of a long (suffix) draft re-read their KV through that XCD's L2 instead of HBM;
   // the row groups a short request does not have exit below after two scalar loads.
   const int m_groups = P.m_groups;
-  const int item = (blockIdx.x / (8 * m_groups)) * 8 + (blockIdx.x & 7);
-  const int row_group = (blockIdx.x >> 3) % m_groups;
+  const int item = (bx / (8 * m_groups)) * 8 + (bx & 7);
+  const int row_group = (bx >> 3) % m_groups;
   if (item >= P.n_items) return;
   const int ridx = item / hgroups;
   const int req = __builtin_amdgcn_readfirstlane(P.req_list ? P.req_list[ridx] : ridx);
@@ -284,7 +288,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((M
   if (row0 >= n_rows) return;
 
   const int n_parts = WH ? P.n_splits : P.n_splits * 4;
-  const int part = WH ? blockIdx.y : blockIdx.y * 4 + wave;
+  const int part = WH ? by : by * 4 + wave;
   const int tiles_total = (ctx + kTile - 1) / kTile;
   const int tiles_per_part = (tiles_total + n_parts - 1) / n_parts;
   const int t_begin = part * tiles_per_part * kTile;
@@ -492,17 +496,17 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((M
       const int rr = row0 + mt * 16 + c16;
       const int pos = rr / G, gq = rr - pos * G;
       const int64_t grow = static_cast<int64_t>(q0 + pos) * Hq + h * G + gq;
-      float* op = P.ws_o + (static_cast<int64_t>(blockIdx.y) * P.total_rows + grow) * kD + 4 * g;
+      float* op = P.ws_o + (static_cast<int64_t>(by) * P.total_rows + grow) * kD + 4 * g;
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt)
         *reinterpret_cast<float4*>(op + dt * 16) =
             make_float4(o_acc[mt][dt][0] * out_scale, o_acc[mt][dt][1] * out_scale, o_acc[mt][dt][2] * out_scale,
                         o_acc[mt][dt][3] * out_scale);
       if (g == 0) {
-        float* mp = P.ws_ml + (static_cast<int64_t>(blockIdx.y) * P.total_rows + grow) * 2;
+        float* mp = P.ws_ml + (static_cast<int64_t>(by) * P.total_rows + grow) * 2;
         mp[0] = m_run[mt] * kLn2;  // the combine kernel works in natural-log units
         mp[1] = l_run[mt];
-        if (blockIdx.y == 0) mark_unused_parts(P, grow);
+        if (by == 0) mark_unused_parts(P, grow);
       }
     }
     return;
@@ -546,7 +550,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((M
   }
   __syncthreads();
   if (wave != 0) return;
-  const int bpart = blockIdx.y;  // one partial per workgroup
+  const int bpart = by;  // one partial per workgroup
 #pragma unroll
   for (int mt = 0; mt < MTQ; ++mt) {
     if (!row_ok[mt]) continue;
@@ -571,11 +575,16 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((M
       float* mp = P.ws_ml + (static_cast<int64_t>(bpart) * P.total_rows + grow) * 2;
       mp[0] = m_all[mt] * kLn2;
       mp[1] = l_all[mt];
-      if (blockIdx.y == 0) mark_unused_parts(P, grow);
+      if (by == 0) mark_unused_parts(P, grow);
     }
   }
 }
 
+template <int MTQ, bool WH, bool KV8, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((MTQ == 1 && NW == 4) ? 3 : 2, (MTQ == 1 && NW == 4) ? 3 : 2))) verify_attn_kernel(AttnParams P) {
+  __shared__ uint4 v_lds_raw[ShortLds<MTQ, NW>::kU4];
+  verify_attn_body<MTQ, WH, KV8, NW>(P, v_lds_raw, blockIdx.x, blockIdx.y);
+}
 
 // One 32-token KV tile (K and V images in LDS at kb / vb, v_tile_off layout) against the NT row tiles of a wave
 // of the long-draft kernels: all NT x 8 score MFMAs first, then a branch-free soft-max over the NT tiles (the
@@ -912,27 +921,30 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                : "memory");
 }
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) verify_attn_long4_kernel(AttnParams P) {
+constexpr int kLong4LdsU4 = kLongRing * 2 * kTile * 16;
+
+// Body of the co-resident long-draft kernel for workgroup (bx, by, bz); lds = kLong4LdsU4 uint4 of LDS.
+__device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint4* lds, const int bx, const int by, const int bz) {
   constexpr int RT = kLongTilesPerWave;
-  __shared__ uint4 kv_lds[kLongRing][2][kTile * 16];  // [ring slot][K|V][32 tokens x 16 chunks]
+  uint4(*kv_lds)[2][kTile * 16] = reinterpret_cast<uint4(*)[2][kTile * 16]>(lds);  // [ring slot][K|V][32 tokens x 16 chunks]
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c16 = lane & 15;
   const int Hkv = P.num_kv_heads, Hq = P.num_q_heads, G = Hq / Hkv;
-  const int ridx = blockIdx.x / Hkv;
-  const int h = blockIdx.x - ridx * Hkv;
+  const int ridx = bx / Hkv;
+  const int h = bx - ridx * Hkv;
   const int req = __builtin_amdgcn_readfirstlane(P.req_list ? P.req_list[ridx] : ridx);
   const int q0 = __builtin_amdgcn_readfirstlane(P.query_start_loc[req]);
   const int q_len = __builtin_amdgcn_readfirstlane(P.query_start_loc[req + 1]) - q0;
   const int ctx = __builtin_amdgcn_readfirstlane(P.seq_lens[req]);
   const int n_rows = q_len * G;
-  const int row_base = blockIdx.z * (4 * RT * 16);
+  const int row_base = bz * (4 * RT * 16);
   if (row_base >= n_rows) return;
 
   const int tiles_total = (ctx + kTile - 1) / kTile;
   const int tiles_per_part = (tiles_total + P.n_splits - 1) / P.n_splits;
-  const int t_begin = blockIdx.y * tiles_per_part * kTile;
+  const int t_begin = by * tiles_per_part * kTile;
   const int t_end = min(ctx, t_begin + tiles_per_part * kTile);
   const int n_iter = t_begin < t_end ? (t_end - t_begin + kTile - 1) / kTile : 0;
 
@@ -1045,17 +1057,44 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int rr = row_base + (wave + 4 * mt) * 16 + c16;
     const int pos = rr / G, gq = rr - pos * G;
     const int64_t grow = static_cast<int64_t>(q0 + pos) * Hq + h * G + gq;
-    float* op = P.ws_o + (static_cast<int64_t>(blockIdx.y) * P.total_rows + grow) * kD + 4 * g;
+    float* op = P.ws_o + (static_cast<int64_t>(by) * P.total_rows + grow) * kD + 4 * g;
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt)
       *reinterpret_cast<float4*>(op + dt * 16) =
           make_float4(o_acc[mt][dt][0], o_acc[mt][dt][1], o_acc[mt][dt][2], o_acc[mt][dt][3]);
     if (g == 0) {
-      float* mp = P.ws_ml + (static_cast<int64_t>(blockIdx.y) * P.total_rows + grow) * 2;
+      float* mp = P.ws_ml + (static_cast<int64_t>(by) * P.total_rows + grow) * 2;
       mp[0] = m_run[mt] * kLn2;
       mp[1] = l_tot[mt];
-      if (blockIdx.y == 0) mark_unused_parts(P, grow);
+      if (by == 0) mark_unused_parts(P, grow);
     }
+  }
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) verify_attn_long4_kernel(AttnParams P) {
+  __shared__ uint4 lds[kLong4LdsU4];
+  verify_attn_long4_body(P, lds, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Short requests and long drafts of one call in ONE launch: workgroups [0, n_long_wg) run the long-draft body,
+// the rest the short-request body.  With two launches on two streams every layer paid a fork and a join event
+// (two extra barrier packets, ~10 us of idle queue each on this runtime); one grid has neither, the long-draft
+// workgroups still sit beside the short ones on the CUs (both bodies are 4 waves, <= 256 VGPRs, 64 KiB LDS: two
+// workgroups per CU), and they come first in the grid so that they are placed before the CUs fill up.
+// The long part is padded to a multiple of 8 workgroups (idle ones), which keeps the short body's XCD-aware item mapping.
+template <bool WH>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+verify_attn_pair_kernel(AttnParams PS, AttnParams PL, int n_long_wg, int n_long_pad, int long_x, int long_y, int short_x) {
+  __shared__ uint4 lds[kLong4LdsU4 > ShortLds<1, 4>::kU4 ? kLong4LdsU4 : ShortLds<1, 4>::kU4];
+  const int b = blockIdx.x;
+  if (b < n_long_pad) {
+    if (b >= n_long_wg) return;
+    const int x = b % long_x, yz = b / long_x;
+    const int y = yz % long_y, z = yz / long_y;
+    verify_attn_long4_body(PL, lds, x, y, z);
+  } else {
+    const int sb = b - n_long_pad;
+    verify_attn_body<1, WH, false, 4>(PS, lds, sb % short_x, sb / short_x);
   }
 }
 
@@ -1270,7 +1309,41 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
     // the caller partitioned the batch: `short_reqs` have q_len * G <= 16 rows (one MFMA tile, one pass),
     // `long_reqs` go through the shared-tile kernel that reads their KV once for up to 192 rows
     SideStream* side = nullptr;
-    const bool overlap = n_short > 0 && n_long > 0;
+    const int per_block_rows_p = 4 * kLongTilesPerWave * 16;
+    const int long_z = (max_rows + per_block_rows_p - 1) / per_block_rows_p;
+    const int short_wg = (n_short * hgroups + 7) / 8 * 8 * n_splits;
+    // one launch for both kinds of request when every workgroup of it can be resident at once (two per CU)
+    bool pair = n_short > 0 && n_long > 0 && !kv8 && !(P.dbg & (4 | 16 | 32));
+    if (pair) {
+      const int room = 2 * 256 - short_wg;
+      const int per_split = n_long * num_kv_heads * long_z;
+      if (room < per_split) {
+        pair = false;
+      } else if (n_splits_long * per_split > room) {
+        n_splits_long = room / per_split;
+      }
+    }
+    if (pair) {
+      AttnParams PL = P;
+      PL.req_list = long_reqs;
+      PL.n_splits = n_splits_long;
+      P.req_list = short_reqs;
+      P.m_groups = 1;
+      P.n_items = n_short * hgroups;
+      const int long_x = n_long * num_kv_heads;
+      const int n_long_wg = long_x * n_splits_long * long_z, n_long_pad = (n_long_wg + 7) / 8 * 8;
+      const int short_x = (P.n_items + 7) / 8 * 8;
+      profile_begin(s);
+      if (wave_heads)
+        hipLaunchKernelGGL(verify_attn_pair_kernel<true>, dim3(static_cast<unsigned>(n_long_pad + short_wg)), dim3(256), 0, s,
+                           P, PL, n_long_wg, n_long_pad, long_x, n_splits_long, short_x);
+      else
+        hipLaunchKernelGGL(verify_attn_pair_kernel<false>, dim3(static_cast<unsigned>(n_long_pad + short_wg)), dim3(256), 0, s,
+                           P, PL, n_long_wg, n_long_pad, long_x, n_splits_long, short_x);
+      profile_end(s);
+      n_short = n_long = 0;  // both done
+    }
+    const bool overlap = n_short > 0 && n_long > 0 && !(P.dbg & 16);
     static const bool short_first = []() { const char* e = getenv("AIC_ATTN_SHORT_FIRST"); return e && e[0] == '1'; }();
     if (n_short > 0) profile_begin(s);  // bench.py's roofline figure: the short-request kernel alone (the begin
                                         // marker sits before the fork so that it delays neither kernel's start)

@@ -210,19 +210,14 @@ def main():
     eng.stats = type(eng.stats)()
     eng.timeline = {}
     attn_bytes = [0.0]
-    attn_bytes_all = [0.0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        # algorithmic KV bytes of one launch of the dominant kernel (verify_attn_kernel): it handles the requests
-        # whose G x q_len query rows fit one 16-row MFMA tile (all but the step's few long suffix drafts, which go
-        # to verify_attn_long_kernel on a side stream): sum_i ctx_i * 2 (K,V) * Hkv_local * D * bytes per element
-        G = eng.hq_local // eng.hkv_local
+        # algorithmic KV bytes of one launch of the dominant kernel (one launch per layer covers every request: the
+        # short-request body and the long-draft body are workgroups of the same grid):
+        # sum_i ctx_i * 2 (K,V) * Hkv_local * D * bytes per element
         kvb = 2 if args.kv_dtype == "auto" else 1
-        ctx_short = sum(len(r.tokens) + len(r.drafts) for r in eng.requests
-                        if r is not None and (1 + len(r.drafts)) * G <= 16)
         ctx_all = sum(len(r.tokens) + len(r.drafts) for r in eng.requests if r is not None)
-        attn_bytes[0] += ctx_short * 2 * eng.hkv_local * shape.head_size * kvb * shape.num_layers
-        attn_bytes_all[0] += ctx_all * 2 * eng.hkv_local * shape.head_size * kvb * shape.num_layers
+        attn_bytes[0] += ctx_all * 2 * eng.hkv_local * shape.head_size * kvb * shape.num_layers
         run_step()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -246,7 +241,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_attention.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch_short_kernel")
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
@@ -277,14 +272,15 @@ def main():
             "tokens_per_request_step": st.emitted / max(args.steps * B, 1),
             "suffix_share_of_drafts": st.suffix_used / max(args.steps * B, 1),
             "host_timeline_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in eng.timeline.items()},
-            "roofline": {"bound": "hbm", "kernel": "verify_attn_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "verify_attn_pair_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_us": avg_launch_us, "launches_timed": launches.value,
                          "launches": args.steps * shape.num_layers,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "kv_bytes_per_layer_all_requests": attn_bytes_all[0] / max(args.steps * shape.num_layers, 1),
-                         "note": "timed with HIP events inside the library around verify_attn_kernel on its own "
-                                 "stream; long suffix drafts run in verify_attn_long_kernel beside it"},
+                         "note": "every %d-th launch timed with a HIP event pair inside the library, on the launch's "
+                                 "stream; the kernel is verify_attn_pair_kernel (short-request and long-draft "
+                                 "workgroups in one grid) or verify_attn_kernel when a step has no long draft"
+                                 % PROFILE_STRIDE},
         }
         if not args.no_cpu_baseline and world == 1:
             cb = cpu_baseline(args, src, shape, spec)
