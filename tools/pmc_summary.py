@@ -1,0 +1,60 @@
+"""HBM traffic of the attention kernels from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of bench.py.
+
+usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <bench.json> > out.json
+
+Corrections follow MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters are in KB (x1024 B); on gfx950
+FETCH_SIZE tallies a 16 B/lane coalesced streaming read at exactly 1/2, so reads = 2 x FETCH_SIZE (checked here
+against a kernel with a known read size, the speculator's one-off weight repack); WRITE_SIZE is exact.
+Per-launch averages skip the warm-up launches of the first step."""
+import csv
+import json
+import sys
+
+
+def per_kernel(path, counter):
+    out = {}
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            out.setdefault(row["Kernel_Name"].split("(")[0], []).append(float(row["Counter_Value"]))
+    return out
+
+
+def main():
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    bench = json.load(open(sys.argv[3]))
+
+    def pick(d, frag):
+        vals = [v for k, v in d.items() if frag in k]
+        return [x for v in vals for x in v]
+
+    res = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python3 bench.py "
+                      "--steps 4 --warmup 2 --no-cpu-baseline",
+           "correction": "gfx950: FETCH_SIZE counts a 16 B/lane coalesced streaming read at exactly 1/2 "
+                         "(MI355X_MICROARCH.md, HBM section): reads = 2 x FETCH_SIZE; WRITE_SIZE exact; unit KB (x1024 B)"}
+    cal = pick(fetch, "repack_bf16_kernel")
+    if cal:
+        res["calibration"] = {"kernel": "repack_bf16_kernel (largest launch = the LM head, vocab x Ds bf16 read once)",
+                              "fetch_size_raw_kb_max": max(cal)}
+    total = 0.0
+    for name, frag in (("pair", "verify_attn_pair_kernel"), ("short", "verify_attn_kernel"), ("combine", "verify_attn_combine_kernel")):
+        f, w = pick(fetch, frag), pick(write, frag)
+        if not f:
+            continue
+        f, w = f[len(f) // 4:], w[len(w) // 4:]
+        rd = 2.0 * 1024.0 * sum(f) / len(f)
+        wr = 1024.0 * sum(w) / max(len(w), 1)
+        res[name] = {"launches": len(f), "fetch_size_raw_kb_avg": sum(f) / len(f), "write_size_kb_avg": sum(w) / max(len(w), 1),
+                     "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr}
+    dom = res.get("pair") or res.get("short")
+    res["kernel"] = "verify_attn_pair_kernel" if "pair" in res else "verify_attn_kernel"
+    res["hbm_bytes_per_launch"] = dom["hbm_read_bytes_per_launch"] + dom["hbm_write_bytes_per_launch"]
+    res["algorithmic_bytes_per_launch"] = bench["roofline"]["algorithmic_bytes_per_launch"]
+    json.dump(res, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()
