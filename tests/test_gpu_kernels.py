@@ -204,6 +204,9 @@ def _attn_case(B, Hq, Hkv, D, q_lens, ctxs, bs, seed):
     dict(B=4, Hq=4, Hkv=1, q_lens=[4, 4, 4, 4], ctxs=[4100, 4099, 5, 4], bs=16),  # SP=8 slice of Llama-8B; ctx == q_len
     dict(B=5, Hq=32, Hkv=8, q_lens=[4, 33, 2, 17, 4], ctxs=[900, 1300, 64, 2100, 33], bs=16),  # mixed LSTM / suffix drafts
     dict(B=2, Hq=64, Hkv=8, q_lens=[33, 3], ctxs=[500, 70], bs=16),   # G = 8: 264 rows -> two 192-row groups
+    dict(B=4, Hq=4, Hkv=1, q_lens=[4, 33, 9, 2], ctxs=[1500, 2600, 130, 64], bs=16),   # SP=8 slice with suffix drafts: short + long in one launch, waves = token ranges
+    dict(B=3, Hq=16, Hkv=2, q_lens=[2, 20, 1], ctxs=[777, 1111, 48], bs=32),           # G = 8, two kv heads, one launch
+    dict(B=40, Hq=32, Hkv=8, q_lens=[4] * 30 + [12, 33, 7, 20, 9, 33, 5, 16, 11, 6], ctxs=[260 + 37 * i for i in range(40)], bs=16),  # many items: the one-launch form does not fit, two launches
 ])
 def test_verify_attention(cfg):
     D = 128
