@@ -184,8 +184,16 @@ class UlyssesContext:
     """SP state of one rank for the stand-alone engine (arcticinference_amd/engine.py): the per-layer
     attention of a step runs on this rank's head slice with the two all-to-alls around it."""
 
-    def __init__(self, sp_size: int, sp_rank: int, group, shape, device="cuda", all_to_all: Optional[Callable] = None):
+    def __init__(self, sp_size: int, sp_rank: int, group, shape, device="cuda", all_to_all: Optional[Callable] = None,
+                 enable_shift_parallel: bool = False, shift_parallel_threshold: int = 512):
         self.sp_size, self.sp_rank, self.group = sp_size, sp_rank, group
+        # shift parallelism (model_runner.py:57-81,237-239): steps of at most `threshold` tokens run the TP = SP x TP
+        # replica, whose attention sees all tokens x this rank's heads straight from the TP-sharded projections (no
+        # all-to-all); the KV cache is the same tensor in both modes (same head slice per rank)
+        self.enable_shift_parallel = enable_shift_parallel
+        self.shift_parallel_threshold = shift_parallel_threshold
+        self.steps_sp = 0
+        self.steps_shift = 0
         lh = local_heads(shape.num_q_heads, shape.num_kv_heads, sp_size)
         if lh.kv_replicated:
             raise NotImplementedError("KV-replicated Ulysses (Hkv < SP) is not on the MI355X path yet (SURVEY §8f-3)")
@@ -201,6 +209,19 @@ class UlyssesContext:
         lo = self.sp_rank * n
         D = s.head_size
         hq, hkv = self.heads.num_q_heads, self.heads.num_kv_heads
+        if use_shift_model(T, sp, self.enable_shift_parallel, self.shift_parallel_threshold):
+            # shift (TP) mode: all tokens x local heads, as the TP-sharded qkv projection of the shift replica
+            # hands them over; no repartition, no collective inside attention
+            self.steps_shift += 1
+            h0, h1 = sp_tp_head_slice(s.num_q_heads, sp, 1, self.sp_rank, 0)
+            q_loc = eng.q_buf[:T].view(T, s.num_q_heads, D)[:, h0:h1]          # strided view, row stride Hq * D
+            out = eng.attn_out[:T].view(T, hq, D)
+            for layer in range(s.num_layers):
+                kv = eng.kv[layer]
+                ops.verify_attention(q_loc, kv[0], kv[1], bt, d_seq, d_qsl, max_q, max_ctx, eng.sm_scale, out=out,
+                                     req_split=eng._req_split, k_scale=eng.kv_scale, v_scale=eng.kv_scale)
+            return
+        self.steps_sp += 1
         # this rank's token slice x all heads, as the dense layers of the target would hand it over
         q = eng.q_buf[lo:lo + n]
         k = eng.k_buf[lo:lo + n]

@@ -49,6 +49,9 @@ def parse_args():
     ap.add_argument("--no-lstm", action="store_true")
     ap.add_argument("--kv-dtype", default="auto", choices=["auto", "fp8"], help="KV cache dtype (auto = bf16, the headline config)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-shift-parallel", action="store_true",
+                    help="N > 1: keep every step on the Ulysses all-to-all path (default: shift parallelism on, threshold "
+                         "512 tokens, the reference's --enable-shift-parallel / --shift-parallel-threshold)")
     ap.add_argument("--rehearse-sp", type=int, default=0,
                     help="single-GPU rehearsal of the SP=N code path: real pack/unpack/attention shapes of rank 0, "
                          "the all-to-all replaced by a local copy (numbers are NOT a multi-GPU measurement)")
@@ -146,12 +149,14 @@ def main():
     tp_group = None
     if world > 1:
         from arcticinference_amd.ulysses import UlyssesContext
-        ulysses = UlyssesContext(world, rank, dist.group.WORLD, shape, device=dev)
+        ulysses = UlyssesContext(world, rank, dist.group.WORLD, shape, device=dev,
+                                 enable_shift_parallel=not args.no_shift_parallel, shift_parallel_threshold=512)
         tp_group = dist.group.WORLD
 
     if world == 1 and args.rehearse_sp > 1:
         from arcticinference_amd.ulysses import UlyssesContext
-        ulysses = UlyssesContext(args.rehearse_sp, 0, None, shape, device=dev, all_to_all=lambda recv, send: recv.copy_(send))
+        ulysses = UlyssesContext(args.rehearse_sp, 0, None, shape, device=dev, all_to_all=lambda recv, send: recv.copy_(send),
+                                 enable_shift_parallel=not args.no_shift_parallel, shift_parallel_threshold=512)
 
     drafter = None
     if not args.no_lstm:
@@ -209,6 +214,8 @@ def main():
     gen_tokens[0] = 0
     eng.stats = type(eng.stats)()
     eng.timeline = {}
+    if ulysses is not None:
+        ulysses.steps_sp = ulysses.steps_shift = 0
     attn_bytes = [0.0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -230,10 +237,34 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    import copy
+    gen_total, stats_snapshot, timeline_snapshot = gen_tokens[0], copy.copy(eng.stats), dict(eng.timeline)
+    steps_shift = ulysses.steps_shift if ulysses is not None else 0
+    steps_sp = ulysses.steps_sp if ulysses is not None else 0
+
+    # N > 1 with shift parallelism: the decode-size steps above ran in shift (TP) mode.  A few extra steps, outside
+    # `value`, with shift off put the Ulysses all-to-all path (2 RCCL all_to_all_single per layer) on the record too.
+    a2a_ms = None
+    if ulysses is not None and ulysses.enable_shift_parallel and steps_shift > 0:
+        ulysses.enable_shift_parallel = False
+        k2 = max(4, min(8, args.steps))
+        run_step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            run_step()
+        barrier()
+        a2a = time.perf_counter() - t1
+        if dist is not None:
+            t = torch.tensor([a2a], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            a2a = float(t.item())
+        a2a_ms = a2a / k2 * 1e3
+        ulysses.enable_shift_parallel = True
 
     if rank == 0:
-        value = gen_tokens[0] / elapsed
-        st = eng.stats
+        value = gen_total / elapsed
+        st = stats_snapshot
         avg_launch_us = tot_us.value / max(launches.value, 1)
         bytes_per_launch = attn_bytes[0] / max(args.steps * shape.num_layers, 1)   # every launch of a step moves the same bytes
         achieved = bytes_per_launch / (avg_launch_us * 1e-6) / 1e9 if launches.value else 0.0
@@ -264,14 +295,17 @@ def main():
                              "attention, acceptance, suffix + LSTM proposal, KV write); target dense layers synthetic"
                              % (shape.num_layers, B, PL, GL, "bf16" if args.kv_dtype == "auto" else "fp8 e4m3")),
                 "global_batch": B, "prompt_len": PL, "gen_len": GL,
-                "parallelism": ("sp%d" % world if world > 1 else ("tp1" if args.rehearse_sp <= 1 else "REHEARSAL sp%d on one GPU" % args.rehearse_sp)),
+                "parallelism": (("sp%d" % world + ("" if args.no_shift_parallel else "+shift(threshold 512 tokens)")) if world > 1
+                                else ("tp1" if args.rehearse_sp <= 1 else "REHEARSAL sp%d on one GPU" % args.rehearse_sp)),
             },
             "tokens_per_s_per_gpu": value / world,
+            "steps_in_shift_mode": steps_shift, "steps_in_sp_mode": steps_sp,
+            "ulysses_all_to_all_path_ms_per_step": a2a_ms,
             "mean_accepted_draft_len": st.accepted / max(st.num_drafts, 1),
             "draft_acceptance_rate": st.accepted / max(st.drafted, 1),
             "tokens_per_request_step": st.emitted / max(args.steps * B, 1),
             "suffix_share_of_drafts": st.suffix_used / max(args.steps * B, 1),
-            "host_timeline_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in eng.timeline.items()},
+            "host_timeline_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in timeline_snapshot.items()},
             "roofline": {"bound": "hbm", "kernel": "verify_attn_pair_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_us": avg_launch_us, "launches_timed": launches.value,

@@ -52,6 +52,17 @@ def _worker(rank, world, port, Hq, Hkv, D, N, out_q):
         # single-process reference over all heads, then this rank's token slice
         ref_all = UlyssesAttention(1, None, Hq, Hkv, D).forward(q, k, v, lambda a, b, c: _full(a, b, c, Hq, Hkv, D, N))
         ok = torch.allclose(out, ref_all[sl], atol=1e-5)
+        # shift (TP) mode of the same rank: all tokens x the rank's heads, no collective; the head slice and the KV
+        # head slice are the ones SP mode uses (KV-cache invariance of shift parallelism, model_runner.py:57-81)
+        from arcticinference_amd.ulysses import sp_tp_head_slice, use_shift_model
+        h0, h1 = sp_tp_head_slice(Hq, world, 1, rank, 0)
+        assert (h1 - h0) == hq and use_shift_model(N, world, True, 512) and not use_shift_model(N, world, True, N - 1)
+        kv0 = h0 // (Hq // Hkv)
+        q_loc = q.view(N, Hq, D)[:, h0:h1].reshape(N, hq * D)
+        k_loc = k.view(N, Hkv, D)[:, kv0:kv0 + hkv].reshape(N, hkv * D)
+        v_loc = v.view(N, Hkv, D)[:, kv0:kv0 + hkv].reshape(N, hkv * D)
+        shift = attn(q_loc, k_loc, v_loc)
+        ok = ok and torch.allclose(shift, ref_all.view(N, Hq, D)[:, h0:h1].reshape(N, hq * D), atol=1e-5)
         out_q.put((rank, bool(ok), tuple(out.shape)))
     finally:
         dist.destroy_process_group()
