@@ -267,6 +267,62 @@ def test_verify_attention_strided_q_and_peaked_softmax():
     assert torch.allclose(got.float().cpu(), want, atol=1e-3, rtol=2 ** -8)
 
 
+def test_verify_attention_full_size_properties():
+    """BASELINE size (B=64, ~4096-token contexts, Llama-8B heads, k=3 and suffix-length drafts), where the fp32 oracle
+    is too slow to be the checker: size-independent properties instead.
+    (1) paging: physically shuffling the KV pages and permuting the block table must not change one bit;
+    (2) two independent code paths (one launch with host-known lengths / the generic kernel + row groups) agree
+        within the kernel tolerance;
+    (3) the output is linear in V: attn(K, V1 + V2) = attn(K, V1) + attn(K, V2) within tolerance;
+    (4) a sample of requests agrees with the oracle."""
+    torch.manual_seed(5)
+    B, Hq, Hkv, D, bs = 64, 32, 8, 128, 16
+    rng = np.random.RandomState(3)
+    q_lens = [4] * 56 + [int(x) for x in rng.randint(6, 34, size=8)]
+    rng.shuffle(q_lens)
+    ctxs = [int(x) for x in rng.randint(3900, 4353, size=B)]
+    max_blocks = max((c + bs - 1) // bs for c in ctxs)
+    nb = B * max_blocks
+    perm = torch.randperm(nb)
+    bt = perm[:B * max_blocks].view(B, max_blocks).to(torch.int32)
+    kc = torch.randn(nb, bs, Hkv, D, device=DEV, dtype=torch.bfloat16)
+    vc = torch.randn(nb, bs, Hkv, D, device=DEV, dtype=torch.bfloat16)
+    v2 = torch.randn(nb, bs, Hkv, D, device=DEV, dtype=torch.bfloat16)
+    T = sum(q_lens)
+    q = torch.randn(T, Hq, D, device=DEV, dtype=torch.bfloat16)
+    qsl = torch.tensor(np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32), device=DEV)
+    seq = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
+    scale = D ** -0.5
+    ops = _ops()
+
+    def run(k, v, table, **kw):
+        return ops.verify_attention(q, k, v, table.to(DEV), seq, qsl, max(q_lens), max(ctxs), scale, **kw).float()
+
+    a = run(kc, vc, bt, q_lens_host=q_lens)
+    # (1) shuffle the pages
+    shuf = torch.randperm(nb)
+    inv = torch.empty_like(shuf)
+    inv[shuf] = torch.arange(nb)
+    a_shuf = run(kc[shuf.to(DEV)], vc[shuf.to(DEV)], inv[bt.long()].to(torch.int32), q_lens_host=q_lens)
+    assert torch.equal(a, a_shuf)
+    # (2) generic path
+    b = run(kc, vc, bt)
+    assert torch.allclose(a, b, atol=1e-3, rtol=2 ** -8), (a - b).abs().max()
+    # (3) linearity in V (the V sum is formed in fp32 and rounded once: compare with matching slack)
+    a2 = run(kc, v2, bt, q_lens_host=q_lens)
+    vs = (vc.float() + v2.float()).to(torch.bfloat16)
+    a12 = run(kc, vs, bt, q_lens_host=q_lens)
+    assert torch.allclose(a12, a + a2, atol=6e-3, rtol=2 ** -6), (a12 - a - a2).abs().max()
+    # (4) oracle on three requests (one of them a long draft)
+    pick = [0, int(np.argmax(q_lens)), B - 1]
+    qs = qsl.cpu().numpy()
+    for i in pick:
+        rows = slice(int(qs[i]), int(qs[i + 1]))
+        want = O.verify_attention(q[rows].cpu(), kc.cpu(), vc.cpu(), bt[i:i + 1], [ctxs[i]],
+                                  np.array([0, q_lens[i]], dtype=np.int32), scale)
+        assert torch.allclose(a[rows].cpu(), want, atol=1e-3, rtol=2 ** -8), (i, (a[rows].cpu() - want).abs().max())
+
+
 # ------------------------------------------------------------------------------------------------
 # A7-A10 LSTM speculator
 # ------------------------------------------------------------------------------------------------
@@ -306,6 +362,23 @@ def test_lstm_speculator_small(B, fp8):
     got = m.generate_proposals(ids.to(DEV), hidden.to(DEV), 3).cpu()
     assert got.shape == (B, 3) and got.dtype == torch.int64
     _check_tokens(got, want, logits, f"B={B} fp8={use_fp8}", ulps=4 if use_fp8 else 1)
+
+
+def test_lstm_speculator_full_size():
+    """The 8B speculator's shapes (Ds = 4096, hidden 4096, vocab 128256), B = 8 rows, bf16 head: tokens against the
+    CPU oracle (a few seconds of CPU GEMM)."""
+    from arcticinference_amd.speculator import ArcticLSTMSpeculator, LSTMSpeculatorConfig, random_lstm_weights
+    cfg = LSTMSpeculatorConfig(vocab_size=128256, input_hidden_dim=4096)
+    ck = random_lstm_weights(cfg, seed=4, std=0.02)
+    m = ArcticLSTMSpeculator(cfg, max_num_seqs=8, device=DEV, quantize_lm_head=False)
+    m.load_weights(ck.items())
+    g = torch.Generator().manual_seed(8)
+    hidden = torch.randn(8, 4096, generator=g).to(torch.bfloat16)
+    ids = torch.randint(0, 128256, (8,), generator=g)
+    want, logits = O.lstm_generate_proposals(O.merge_lstm_checkpoint(ck), ids, hidden, 3, 3, True, fp8_head=False,
+                                             return_logits=True)
+    got = m.generate_proposals(ids.to(DEV), hidden.to(DEV), 3).cpu()
+    _check_tokens(got, want, logits, "full size")
 
 
 def test_lstm_hidden_index_and_errors():
