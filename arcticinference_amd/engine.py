@@ -201,8 +201,11 @@ class HotPathEngine:
 
         # one pinned staging buffer and ONE host->device copy for all of the step's small index arrays
         slot_map = self._slot_mapping(live, reqs, q_len, qsl, T)
-        parts = [ctx, qsl, draft_flat, np.cumsum(n_draft), plant_tok, target_rows, bonus_rows, np.asarray(live), slot_map]
-        kinds = [np.int32, np.int32, np.int32, np.int32, np.int64, np.int64, np.int64, np.int64, np.int64]
+        G = self.hq_local // self.hkv_local
+        so = ops.split_order(q_len, G)            # short / long request lists of the attention call
+        parts = [ctx, qsl, draft_flat, np.cumsum(n_draft), plant_tok, target_rows, bonus_rows, np.asarray(live), slot_map,
+                 so[0] if so is not None else np.zeros(0, np.int32)]
+        kinds = [np.int32, np.int32, np.int32, np.int32, np.int64, np.int64, np.int64, np.int64, np.int64, np.int32]
         offs, nbytes = [], 0
         for a, k in zip(parts, kinds):
             nbytes = (nbytes + 15) & ~15
@@ -226,7 +229,11 @@ class HotPathEngine:
         # (a) KV of the step's tokens for every layer in one launch (A16), then (b) verify attention per layer
         self._write_kv(d_slots, T)
         _mark('host_prepare')
-        self._req_split = ops.split_requests(q_len, self.hq_local // self.hkv_local, dev)
+        self._req_split = None
+        if so is not None:
+            order_dev = dview(9, torch.int32)
+            self._req_split = (order_dev[:so[1]], so[1], order_dev[so[1]:], len(so[0]) - so[1])
+        self._stream = int(torch.cuda.current_stream().cuda_stream)   # looked up once per step, not once per layer
         self._attention_layers(T, bt, d_seq, d_qsl, max_q, max_ctx)
 
         _mark('enqueue_attention')
@@ -367,9 +374,9 @@ class HotPathEngine:
             self._one = [torch.ones(1, device=self.device) for _ in range(s.num_layers)]
             self._kc = [kv[0] for kv in self.kv]
             self._vc = [kv[1] for kv in self.kv]
-        scales = self._one if self.kv_scale is None else [self.kv_scale] * s.num_layers
-        ops.reshape_and_cache_flash_bulk(self._kv_new[0, :T], self._kv_new[1, :T], self._kc, self._vc, d_slots,
-                                         self.kv_cache_dtype, scales, scales, self.hkv_local, s.head_size)
+            scales = self._one if self.kv_scale is None else [self.kv_scale] * s.num_layers
+            self._kv_writer = ops.KvBulkWriter(self._kc, self._vc, self.kv_cache_dtype, scales, scales, self.hkv_local, s.head_size)
+        self._kv_writer(self._kv_new[0, :T], self._kv_new[1, :T], d_slots)
 
     def _attention_layers(self, T, bt, d_seq, d_qsl, max_q, max_ctx) -> None:
         s = self.shape
@@ -379,6 +386,7 @@ class HotPathEngine:
             for layer in range(s.num_layers):
                 kv = self.kv[layer]
                 ops.verify_attention(q, kv[0], kv[1], bt, d_seq, d_qsl, max_q, max_ctx, self.sm_scale, out=out,
-                                     req_split=self._req_split, k_scale=self.kv_scale, v_scale=self.kv_scale)
+                                     req_split=self._req_split, k_scale=self.kv_scale, v_scale=self.kv_scale,
+                                     stream=self._stream)
         else:
             self.ulysses.attention_layers(self, T, bt, d_seq, d_qsl, max_q, max_ctx)

@@ -29,40 +29,61 @@ def _need_cuda(*ts: torch.Tensor) -> None:
 _KV_DTYPES = {"auto": None, "fp8": N.DT_FP8_E4M3, "fp8_e4m3": N.DT_FP8_E4M3, "fp8_e5m2": N.DT_FP8_E5M2}
 
 
+class KvBulkWriter:
+    """reshape_and_cache_flash_bulk for a fixed set of caches: the checks and the per-layer pointer tables of the
+    wrapper are done once (an engine calls it every step with the same caches)."""
+
+    def __init__(self, key_caches: List[torch.Tensor], value_caches: List[torch.Tensor], kv_cache_dtype: str,
+                 k_scales: List[torch.Tensor], v_scales: List[torch.Tensor], num_heads: int, head_size: int):
+        L = len(key_caches)
+        # same checks as the reference launcher (kernels.cu:103-106)
+        if not (L == len(value_caches) == len(k_scales) == len(v_scales)):
+            raise RuntimeError("key_caches, value_caches, k_scales and v_scales must have the same length")
+        if kv_cache_dtype not in _KV_DTYPES:
+            raise RuntimeError(f"unsupported kv cache dtype '{kv_cache_dtype}'")
+        self.L = L
+        if L == 0:
+            return
+        _need_cuda(*key_caches, *value_caches)
+        self.kvd = _KV_DTYPES[kv_cache_dtype]
+        self.cache_dtype = key_caches[0].dtype
+        self.block_size = int(key_caches[0].size(1))
+        self.block_stride = int(key_caches[0].stride(0))
+        if self.block_stride != value_caches[0].stride(0):
+            raise RuntimeError("key and value caches must share the block stride")
+        VP = ctypes.c_void_p * L
+        self._keep = (list(key_caches), list(value_caches), list(k_scales), list(v_scales))   # the tables hold raw pointers
+        self.kc = VP(*[c.data_ptr() for c in key_caches])
+        self.vc = VP(*[c.data_ptr() for c in value_caches])
+        self.ks = VP(*[s.data_ptr() for s in k_scales])
+        self.vs = VP(*[s.data_ptr() for s in v_scales])
+        self.num_heads, self.head_size = int(num_heads), int(head_size)
+
+    def __call__(self, keys: torch.Tensor, values: torch.Tensor, slot_mapping: torch.Tensor, stream: Optional[int] = None) -> None:
+        if self.L == 0:
+            return
+        _need_cuda(keys, values, slot_mapping)
+        if slot_mapping.dtype != torch.int64:
+            raise RuntimeError("slot_mapping must be int64")
+        src = N.torch_dtype_code(keys.dtype)
+        kvd = self.kvd
+        if kvd is None:
+            kvd = src
+            if self.cache_dtype != keys.dtype:
+                raise RuntimeError("kv_cache_dtype 'auto' needs caches of the source dtype")
+        N.check(N.lib().aic_reshape_and_cache_flash_bulk(
+            keys.data_ptr(), values.data_ptr(), self.kc, self.vc, slot_mapping.data_ptr(), slot_mapping.size(0), self.L,
+            self.num_heads, self.head_size, self.block_size, self.block_stride, int(keys.stride(0)),
+            int(values.stride(0)), src, kvd, self.ks, self.vs, N.current_stream_ptr() if stream is None else stream))
+
+
 def reshape_and_cache_flash_bulk(keys: torch.Tensor, values: torch.Tensor, key_caches: List[torch.Tensor],
                                  value_caches: List[torch.Tensor], slot_mapping: torch.Tensor, kv_cache_dtype: str,
                                  k_scales: List[torch.Tensor], v_scales: List[torch.Tensor], num_heads: int,
                                  head_size: int) -> None:
-    L = len(key_caches)
-    if L == 0:
+    if len(key_caches) == 0:
         return
-    # same checks as the reference launcher (kernels.cu:103-106)
-    if not (L == len(value_caches) == len(k_scales) == len(v_scales)):
-        raise RuntimeError("key_caches, value_caches, k_scales and v_scales must have the same length")
-    if kv_cache_dtype not in _KV_DTYPES:
-        raise RuntimeError(f"unsupported kv cache dtype '{kv_cache_dtype}'")
-    _need_cuda(keys, values, slot_mapping, *key_caches, *value_caches)
-    if slot_mapping.dtype != torch.int64:
-        raise RuntimeError("slot_mapping must be int64")
-    src = N.torch_dtype_code(keys.dtype)
-    kvd = _KV_DTYPES[kv_cache_dtype]
-    if kvd is None:
-        kvd = src
-        if key_caches[0].dtype != keys.dtype:
-            raise RuntimeError("kv_cache_dtype 'auto' needs caches of the source dtype")
-    block_size = key_caches[0].size(1)
-    block_stride = key_caches[0].stride(0)
-    if block_stride != value_caches[0].stride(0):
-        raise RuntimeError("key and value caches must share the block stride")
-    VP = ctypes.c_void_p * L
-    kc = VP(*[c.data_ptr() for c in key_caches])
-    vc = VP(*[c.data_ptr() for c in value_caches])
-    ks = VP(*[s.data_ptr() for s in k_scales])
-    vs = VP(*[s.data_ptr() for s in v_scales])
-    N.check(N.lib().aic_reshape_and_cache_flash_bulk(
-        keys.data_ptr(), values.data_ptr(), kc, vc, slot_mapping.data_ptr(), slot_mapping.size(0), L,
-        int(num_heads), int(head_size), int(block_size), int(block_stride), int(keys.stride(0)),
-        int(values.stride(0)), src, kvd, ks, vs, N.current_stream_ptr()))
+    KvBulkWriter(key_caches, value_caches, kv_cache_dtype, k_scales, v_scales, num_heads, head_size)(keys, values, slot_mapping)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -132,11 +153,13 @@ def verify_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
                      seq_lens: torch.Tensor, query_start_loc: torch.Tensor, max_q_len: int, max_seq_len: int,
                      sm_scale: float, out: Optional[torch.Tensor] = None, num_splits_max: int = 64,
                      q_lens_host: Optional[Sequence[int]] = None, req_split=None,
-                     k_scale: Optional[torch.Tensor] = None, v_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     k_scale: Optional[torch.Tensor] = None, v_scale: Optional[torch.Tensor] = None,
+                     stream: Optional[int] = None) -> torch.Tensor:
     """q [T, Hq, D] (token stride may exceed Hq*D: a view into an all-to-all receive buffer works),
     caches [num_blocks, block_size, Hkv, D] in bf16, or float8_e4m3fn with per-tensor `k_scale` / `v_scale`
     (device scalars, the scales A16 divided by); returns [T, Hq, D].  `q_lens_host` (the per-request query
-    lengths, which vLLM has on the host) lets long drafts take the shared-tile kernel."""
+    lengths, which vLLM has on the host) lets long drafts take the shared-tile kernel.  `stream`: raw HIP stream
+    handle (default: torch's current stream; a caller that issues one call per layer looks it up once)."""
     _need_cuda(q, k_cache, v_cache, block_table, seq_lens, query_start_loc)
     T, Hq, D = q.shape
     nb, bs, Hkv, D2 = k_cache.shape
@@ -155,22 +178,32 @@ def verify_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
         _ptr(v_scale), block_table.data_ptr(), block_table.size(1), seq_lens.data_ptr(), query_start_loc.data_ptr(), B, T,
         int(max_q_len), Hq, Hkv, D, bs, float(sm_scale), out.data_ptr(), out.stride(0), ws.data_ptr(), ws.numel(),
         int(max_seq_len), _ptr(short) if n_short else None, n_short, _ptr(long_) if n_long else None, n_long,
-        N.current_stream_ptr()))
+        N.current_stream_ptr() if stream is None else stream))
     return out
 
 
-def split_requests(q_lens_host: Sequence[int], group_size: int, device):
-    """Partition a batch by query length for aic_verify_attention_ex: (short_ids, n_short, long_ids, n_long) with
-    device int32 id lists, or None when every request fits one 16-row MFMA tile (q_len * Hq/Hkv <= 16).
-    Build it once per engine step and pass it to every layer's verify_attention call."""
+def split_order(q_lens_host: Sequence[int], group_size: int):
+    """Host half of split_requests: (request ids with the short ones first, as int32; number of short requests), or
+    None when every request fits one 16-row MFMA tile (q_len * Hq/Hkv <= 16)."""
     import numpy as np
     ql = np.asarray(q_lens_host)
     is_short = ql * group_size <= 16
     if is_short.all():
         return None
     order = np.concatenate([np.nonzero(is_short)[0], np.nonzero(~is_short)[0]]).astype(np.int32)
-    n_short = int(is_short.sum())
-    lists = torch.from_numpy(order).to(device, non_blocking=True)
+    return order, int(is_short.sum())
+
+
+def split_requests(q_lens_host: Sequence[int], group_size: int, device, order_dev: Optional[torch.Tensor] = None):
+    """Partition a batch by query length for aic_verify_attention_ex: (short_ids, n_short, long_ids, n_long) with
+    device int32 id lists, or None when every request is short.  Build it once per engine step and pass it to every
+    layer's verify_attention call.  `order_dev`: the id list already on the device (a caller that stages all of a
+    step's index arrays in one copy passes split_order()'s array through that copy)."""
+    so = split_order(q_lens_host, group_size)
+    if so is None:
+        return None
+    order, n_short = so
+    lists = order_dev if order_dev is not None else torch.from_numpy(order).to(device, non_blocking=True)
     return lists[:n_short], n_short, lists[n_short:], len(order) - n_short
 
 

@@ -219,7 +219,7 @@ class UlyssesContext:
             for layer in range(s.num_layers):
                 kv = eng.kv[layer]
                 ops.verify_attention(q_loc, kv[0], kv[1], bt, d_seq, d_qsl, max_q, max_ctx, eng.sm_scale, out=out,
-                                     req_split=eng._req_split, k_scale=eng.kv_scale, v_scale=eng.kv_scale)
+                                     req_split=eng._req_split, k_scale=eng.kv_scale, v_scale=eng.kv_scale, stream=eng._stream)
             return
         self.steps_sp += 1
         # this rank's token slice x all heads, as the dense layers of the target would hand it over
@@ -232,7 +232,7 @@ class UlyssesContext:
             out = eng.attn_out[:Tp].view(Tp, hq, D)
             qv = q_.unflatten(1, (hq, D))   # strided view into the all-to-all receive buffer
             ops.verify_attention(qv[:T], kv[0], kv[1], bt, d_seq, d_qsl, max_q, max_ctx, eng.sm_scale, out=out[:T],
-                                 req_split=eng._req_split, k_scale=eng.kv_scale, v_scale=eng.kv_scale)
+                                 req_split=eng._req_split, k_scale=eng.kv_scale, v_scale=eng.kv_scale, stream=eng._stream)
             return eng.attn_out[:Tp]
 
         for layer in range(s.num_layers):
