@@ -61,15 +61,56 @@ class StepStats:
     suffix_used: int = 0
 
 
+class _PendingDrafts:
+    """LSTM draft tokens of one step on their way to the host (pinned buffer + event).  The next step does not need
+    their VALUES on the host (it fills them into its input ids on the device), so nobody waits for this copy on the
+    critical path; whoever reads `RequestState.drafts` first resolves it."""
+
+    def __init__(self, pinned: torch.Tensor, event, rows):
+        self.pinned, self.event, self.rows = pinned, event, rows     # rows: [(request, row in the LSTM output, k)]
+        self.done = False
+
+    def resolve(self) -> None:
+        if self.done:
+            return
+        self.done = True
+        self.event.synchronize()
+        host = self.pinned.numpy()
+        for r, row, k in self.rows:
+            if r._pending is self:
+                r._drafts = host[row, :k].tolist()
+                r._pending = None
+
+
 class RequestState:
-    __slots__ = ("req_id", "tokens", "num_prompt", "drafts", "blocks")
+    __slots__ = ("req_id", "tokens", "num_prompt", "_drafts", "_pending", "draft_row", "blocks")
 
     def __init__(self, req_id, prompt: Sequence[int], blocks: np.ndarray):
         self.req_id = req_id
         self.tokens: List[int] = list(prompt)   # prompt + every sampled token (token_ids_cpu row)
         self.num_prompt = len(prompt)
-        self.drafts: List[int] = []
+        self._drafts: List[int] = []
+        self._pending: Optional[_PendingDrafts] = None
+        self.draft_row = -1                      # row of this request in the LSTM output its drafts come from
         self.blocks = blocks
+
+    @property
+    def drafts(self) -> List[int]:
+        """Draft token ids scheduled for the next step (spec_token_ids).  LSTM drafts may still be in flight from the
+        device; reading them here waits for that copy."""
+        if self._pending is not None:
+            self._pending.resolve()
+        return self._drafts
+
+    @drafts.setter
+    def drafts(self, value: List[int]) -> None:
+        self._drafts = value
+        self._pending = None
+        self.draft_row = -1
+
+    @property
+    def num_drafts(self) -> int:
+        return len(self._drafts)
 
 
 class HotPathEngine:
@@ -180,19 +221,32 @@ class HotPathEngine:
         if B == 0:
             return []
         reqs = [self.requests[i] for i in live]
-        n_draft = np.array([len(r.drafts) for r in reqs], dtype=np.int32)
+        n_draft = np.fromiter((len(r._drafts) for r in reqs), dtype=np.int32, count=B)
         q_len = n_draft + 1
         T = int(q_len.sum())
         qsl = np.zeros(B + 1, dtype=np.int32)
         np.cumsum(q_len, out=qsl[1:])
         # context after this step's tokens are written: everything sampled so far + the drafts
-        ctx = np.array([len(r.tokens) + len(r.drafts) for r in reqs], dtype=np.int32)
+        ctx = np.fromiter((len(r.tokens) for r in reqs), dtype=np.int32, count=B) + n_draft
         max_q, max_ctx = int(q_len.max()), int(ctx.max())
 
         # planted verify logits: row (request i, position p) gets the target's token for that position
         truth = [next_truth(r, int(q_len[i])) for i, r in enumerate(reqs)]
         plant_tok = np.concatenate([np.asarray(t, dtype=np.int64) for t in truth])
-        draft_flat = np.concatenate([np.asarray(r.drafts, dtype=np.int32) for r in reqs]) if n_draft.sum() else np.zeros(0, np.int32)
+        # draft ids: suffix drafts are host lists; LSTM drafts of the previous step are still on the device (their
+        # host copy is in flight and nobody waits for it here): placeholders now, filled on the device below
+        draft_flat = np.concatenate([np.asarray(r._drafts, dtype=np.int32) for r in reqs]) if n_draft.sum() else np.zeros(0, np.int32)
+        cu_draft = np.cumsum(n_draft)
+        fill_pos, fill_src = [], []
+        prev_lstm = getattr(self, "_lstm_prev", None)
+        if prev_lstm is not None:
+            kcols = prev_lstm.shape[1]
+            for i, r in enumerate(reqs):
+                if r._pending is not None and not r._pending.done:
+                    k = int(n_draft[i])
+                    base = int(cu_draft[i]) - k
+                    fill_pos.extend(range(base, base + k))
+                    fill_src.extend(range(r.draft_row * kcols, r.draft_row * kcols + k))
         # target rows = all but the last row of each request; bonus row = the last one (model_runner.py:394-404)
         is_bonus = np.zeros(T, dtype=bool)
         is_bonus[qsl[1:] - 1] = True
@@ -203,9 +257,10 @@ class HotPathEngine:
         slot_map = self._slot_mapping(live, reqs, q_len, qsl, T)
         G = self.hq_local // self.hkv_local
         so = ops.split_order(q_len, G)            # short / long request lists of the attention call
-        parts = [ctx, qsl, draft_flat, np.cumsum(n_draft), plant_tok, target_rows, bonus_rows, np.asarray(live), slot_map,
-                 so[0] if so is not None else np.zeros(0, np.int32)]
-        kinds = [np.int32, np.int32, np.int32, np.int32, np.int64, np.int64, np.int64, np.int64, np.int64, np.int32]
+        parts = [ctx, qsl, draft_flat, cu_draft, plant_tok, target_rows, bonus_rows, np.asarray(live), slot_map,
+                 so[0] if so is not None else np.zeros(0, np.int32), np.asarray(fill_pos, np.int64), np.asarray(fill_src, np.int64)]
+        kinds = [np.int32, np.int32, np.int32, np.int32, np.int64, np.int64, np.int64, np.int64, np.int64, np.int32,
+                 np.int64, np.int64]
         offs, nbytes = [], 0
         for a, k in zip(parts, kinds):
             nbytes = (nbytes + 15) & ~15
@@ -225,6 +280,8 @@ class HotPathEngine:
         d_seq, d_qsl, d_draft, d_cu = (dview(i, torch.int32) for i in range(4))
         d_plant, d_trows, d_brows, slots, d_slots = (dview(i, torch.int64) for i in range(4, 9))
         bt = self.block_table.index_select(0, slots) if B != self.max_num_seqs else self.block_table
+        if fill_pos:
+            d_draft.index_copy_(0, dview(10, torch.int64), prev_lstm.reshape(-1).index_select(0, dview(11, torch.int64)).to(torch.int32))
 
         # (a) KV of the step's tokens for every layer in one launch (A16), then (b) verify attention per layer
         self._write_kv(d_slots, T)
@@ -301,20 +358,36 @@ class HotPathEngine:
             with torch.cuda.stream(self._suffix_stream):
                 suffix = self._propose_suffix(live_arr, reqs, n_emit)
             _mark('suffix_speculate_roundtrip')
-        # (f) merge (:555-566, :595-601)
-        lstm_host = lstm_out.cpu().numpy() if lstm_out is not None else None
-        _mark('wait_lstm')
+        # (f) merge (:555-566, :595-601).  The LSTM tokens start their copy to the host (the reference's `.cpu()`,
+        # arctic_proposer.py:166) but nothing here waits for it: which requests take the LSTM draft, and how many
+        # tokens, is known from the suffix result alone, and the next step fills the ids in on the device.
+        pend = None
+        if lstm_out is not None:
+            if not hasattr(self, "_lstm_pin"):
+                self._lstm_pin = [torch.empty(self.max_num_seqs, lstm_out.shape[1], dtype=lstm_out.dtype).pin_memory()
+                                  for _ in range(2)]
+                self._lstm_flip = 0
+            self._lstm_flip ^= 1
+            pin = self._lstm_pin[self._lstm_flip][:B]      # two buffers: the previous step's copy may still be unread
+            pin.copy_(lstm_out, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            pend = _PendingDrafts(pin, ev, [])
+        self._lstm_prev = lstm_out
         min_score = 0 if spec.method == "suffix" else spec.num_speculative_tokens
         for i, r in enumerate(reqs):
             room = self.max_model_len - len(r.tokens) - 1
-            drafts: List[int] = []
             if suffix is not None and suffix[1][i] > 0 and suffix[2][i] >= min_score:
-                drafts = suffix[0][i, :suffix[1][i]].tolist()
+                r.drafts = suffix[0][i, :suffix[1][i]].tolist()[:max(room, 0)]
                 self.stats.suffix_used += 1
-            elif lstm_host is not None and n_emit[i]:
-                k = min(spec.num_speculative_tokens, room)
-                drafts = lstm_host[i, :max(k, 0)].tolist()
-            r.drafts = drafts[:max(room, 0)]
+            elif pend is not None and n_emit[i]:
+                k = max(min(spec.num_speculative_tokens, room), 0)
+                r.drafts = [0] * k                          # placeholders until the copy lands
+                if k:
+                    r._pending, r.draft_row = pend, i
+                    pend.rows.append((r, i, k))
+            else:
+                r.drafts = []
         _mark('host_merge')
         return emitted
 
