@@ -688,215 +688,22 @@ __device__ __forceinline__ void long_tile_compute(const char* kb, const char* vb
     }
 }
 
-// ------------------------------------------------------------------------------------------------------
-// Long-draft variant (suffix drafts: up to 33 query positions = 132 rows at G = 4).  A workgroup is 8 waves on
-// ONE kv head and one token range: waves 0-3 compute, each on its own row tiles (wave w owns row tiles
-// w, w+4, w+8 -> up to 192 rows per workgroup) against a 32-token K/V tile in LDS, so the KV bytes of a long
-// request are read once instead of once per row group; waves 4-7 only move data: they keep THREE tiles in
-// flight in a ring of register sets (row-contiguous 16-byte loads) and drop one tile per iteration into the
-// free half of a double-buffered LDS image (dequantising an fp8 cache on the way).  The compute waves never
-// wait on HBM; with the loads issued by the compute waves themselves (one tile ahead) the kernel ran at HBM
-// latency per tile (~5 us) although its MFMA work per tile is ~0.5 us.  One barrier per tile.
-// ------------------------------------------------------------------------------------------------------
 constexpr int kLongTilesPerWave = 3;
 
-template <bool KV8>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) verify_attn_long_kernel(AttnParams P) {
-  constexpr int RT = kLongTilesPerWave;
-  __shared__ uint4 kv_lds[2][2][kTile * 16];  // [buffer][K|V][32 tokens x 16 chunks]
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int g = lane >> 4, c16 = lane & 15;
-  const int Hkv = P.num_kv_heads, Hq = P.num_q_heads, G = Hq / Hkv;
-  const int ridx = blockIdx.x / Hkv;
-  const int h = blockIdx.x - ridx * Hkv;
-  const int req = __builtin_amdgcn_readfirstlane(P.req_list ? P.req_list[ridx] : ridx);
-  const int q0 = __builtin_amdgcn_readfirstlane(P.query_start_loc[req]);
-  const int q_len = __builtin_amdgcn_readfirstlane(P.query_start_loc[req + 1]) - q0;
-  const int ctx = __builtin_amdgcn_readfirstlane(P.seq_lens[req]);
-  const int n_rows = q_len * G;
-  const int row_base = blockIdx.z * (4 * RT * 16);  // row groups of 192 rows (only for G x q_len > 192)
-  if (row_base >= n_rows) return;
-
-  const int tiles_total = (ctx + kTile - 1) / kTile;
-  const int tiles_per_part = (tiles_total + P.n_splits - 1) / P.n_splits;
-  const int t_begin = blockIdx.y * tiles_per_part * kTile;
-  const int t_end = min(ctx, t_begin + tiles_per_part * kTile);
-  const int n_iter = t_begin < t_end ? (t_end - t_begin + kTile - 1) / kTile : 0;
-
-  const int64_t kv_row = static_cast<int64_t>(Hkv) * kD;
-  const_i32_ptr btab = (const_i32_ptr)(P.block_table + static_cast<int64_t>(req) * P.max_blocks);
-  const int bs = P.block_size;
-  const int last_group = (ctx - 1) & ~15;
-
-  if (wave >= 4) {
-    // ================================ loader waves ================================
-    const char* kc = reinterpret_cast<const char*>(P.k_cache);
-    const char* vc = reinterpret_cast<const char*>(P.v_cache);
-    const int lt = threadIdx.x - 256;
-    // bf16: thread moves 16-byte chunks lt and lt + 256 of K and of V (token = chunk / 16);
-    // fp8 : the tile is 256 chunks of 16 bytes, one per thread (token = lt / 8), dequantised at the LDS store
-    const int tk0 = KV8 ? lt >> 3 : lt >> 4, tk1 = tk0 + 16;
-    const int ch = KV8 ? lt & 7 : lt & 15;
-    uint4 ak0, ak1, av0, av1, bk0, bk1, bv0, bv1, ck0, ck1, cv0, cv1;
-    if (KV8) ak1 = av1 = bk1 = bv1 = ck1 = cv1 = make_uint4(0, 0, 0, 0);
-#define AIC_LONG_LOAD(set_, tt_)                                                                                \
-  {                                                                                                             \
-    const int f0_ = min((tt_), last_group), f1_ = min((tt_) + 16, last_group);                                  \
-    const int64_t b0_ = static_cast<int64_t>(btab[f0_ / bs]) * P.block_stride + static_cast<int64_t>(f0_ % bs) * kv_row + h * kD; \
-    const int64_t b1_ = static_cast<int64_t>(btab[f1_ / bs]) * P.block_stride + static_cast<int64_t>(f1_ % bs) * kv_row + h * kD; \
-    if (KV8) {                                                                                                  \
-      const bool hi_ = tk0 >= 16;                                                                               \
-      const int64_t o_ = (hi_ ? b1_ : b0_) + static_cast<int64_t>(min((tt_) + tk0, ctx - 1) - (hi_ ? f1_ : f0_)) * kv_row + 16 * ch; \
-      set_##k0 = *reinterpret_cast<const uint4*>(kc + o_);                                                      \
-      set_##v0 = *reinterpret_cast<const uint4*>(vc + o_);                                                      \
-    } else {                                                                                                    \
-      const int64_t o0_ = b0_ + static_cast<int64_t>(min((tt_) + tk0, ctx - 1) - f0_) * kv_row + 8 * ch;       \
-      const int64_t o1_ = b1_ + static_cast<int64_t>(min((tt_) + tk1, ctx - 1) - f1_) * kv_row + 8 * ch;       \
-      set_##k0 = *reinterpret_cast<const uint4*>(kc + 2 * o0_);                                                 \
-      set_##k1 = *reinterpret_cast<const uint4*>(kc + 2 * o1_);                                                 \
-      set_##v0 = *reinterpret_cast<const uint4*>(vc + 2 * o0_);                                                 \
-      set_##v1 = *reinterpret_cast<const uint4*>(vc + 2 * o1_);                                                 \
-    }                                                                                                           \
-  }
-#define AIC_LONG_STORE(set_, buf_)                                                                              \
-  {                                                                                                             \
-    char* kb_ = reinterpret_cast<char*>(kv_lds[buf_][0]);                                                       \
-    char* vb_ = reinterpret_cast<char*>(kv_lds[buf_][1]);                                                       \
-    if (KV8) {                                                                                                  \
-      *reinterpret_cast<bf16x8*>(kb_ + v_tile_off(tk0, 2 * ch)) = fp8x8_to_bf16x8(set_##k0.x, set_##k0.y);      \
-      *reinterpret_cast<bf16x8*>(kb_ + v_tile_off(tk0, 2 * ch + 1)) = fp8x8_to_bf16x8(set_##k0.z, set_##k0.w);  \
-      *reinterpret_cast<bf16x8*>(vb_ + v_tile_off(tk0, 2 * ch)) = fp8x8_to_bf16x8(set_##v0.x, set_##v0.y);      \
-      *reinterpret_cast<bf16x8*>(vb_ + v_tile_off(tk0, 2 * ch + 1)) = fp8x8_to_bf16x8(set_##v0.z, set_##v0.w);  \
-    } else {                                                                                                    \
-      *reinterpret_cast<uint4*>(kb_ + v_tile_off(tk0, ch)) = set_##k0;                                          \
-      *reinterpret_cast<uint4*>(kb_ + v_tile_off(tk1, ch)) = set_##k1;                                          \
-      *reinterpret_cast<uint4*>(vb_ + v_tile_off(tk0, ch)) = set_##v0;                                          \
-      *reinterpret_cast<uint4*>(vb_ + v_tile_off(tk1, ch)) = set_##v1;                                          \
-    }                                                                                                           \
-  }
-    // tile j of the range starts at token t_begin + 32 j; loads past the range are clamped into the context
-    // (valid addresses, never consumed)
-#define AIC_TILE(j_) (t_begin + (j_) * kTile)
-    if (n_iter > 0) {
-      AIC_LONG_LOAD(a, AIC_TILE(0))
-      AIC_LONG_STORE(a, 0)
-      AIC_LONG_LOAD(a, AIC_TILE(1))
-      AIC_LONG_LOAD(b, AIC_TILE(2))
-      AIC_LONG_LOAD(c, AIC_TILE(3))
-    }
-    // iteration i: (barrier) tile i+1 -> LDS buffer (i+1)&1, then re-arm that register set with tile i+4
-    for (int i = 0; i < n_iter; i += 3) {
-      __syncthreads();
-      if (i + 1 < n_iter) AIC_LONG_STORE(a, (i + 1) & 1)
-      AIC_LONG_LOAD(a, AIC_TILE(i + 4))
-      if (i + 1 >= n_iter) break;
-      __syncthreads();
-      if (i + 2 < n_iter) AIC_LONG_STORE(b, (i + 2) & 1)
-      AIC_LONG_LOAD(b, AIC_TILE(i + 5))
-      if (i + 2 >= n_iter) break;
-      __syncthreads();
-      if (i + 3 < n_iter) AIC_LONG_STORE(c, (i + 3) & 1)
-      AIC_LONG_LOAD(c, AIC_TILE(i + 6))
-    }
-#undef AIC_TILE
-#undef AIC_LONG_LOAD
-#undef AIC_LONG_STORE
-    return;
-  }
-
-  // ================================ compute waves ================================
-  const float scale_log2 = P.sm_scale * kLog2e * (KV8 ? *P.k_scale : 1.0f);
-  const float out_scale = KV8 ? *P.v_scale : 1.0f;
-  uint4 qf[RT][4];
-  int row_pos[RT];
-  bool row_ok[RT];
-#pragma unroll
-  for (int mt = 0; mt < RT; ++mt) {
-    const int rr = row_base + (wave + 4 * mt) * 16 + c16;
-    row_ok[mt] = rr < n_rows;
-    const int rc = min(rr, n_rows - 1);
-    const int pos = rc / G, gq = rc - pos * G;
-    row_pos[mt] = pos;
-    const uint16_t* qp = P.q + static_cast<int64_t>(q0 + pos) * P.q_stride + static_cast<int64_t>(h * G + gq) * kD + 8 * g;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qf[mt][s] = *reinterpret_cast<const uint4*>(qp + 32 * s);
-  }
-  float m_run[RT], l_run[RT];
-  f32x4 o_acc[RT][8];
-#pragma unroll
-  for (int mt = 0; mt < RT; ++mt) {
-    m_run[mt] = -INFINITY;
-    l_run[mt] = 0.0f;
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) o_acc[mt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-
-  // row tiles this wave really owns (tile index wave + 4 mt < ceil(rows / 16)); the others are skipped
-  const int n_row_tiles = (min(n_rows - row_base, 4 * RT * 16) + 15) >> 4;
-  const int my_tiles = __builtin_amdgcn_readfirstlane(n_row_tiles > wave ? (n_row_tiles - wave + 3) >> 2 : 0);
-
-  // One instance of the tile loop per row-tile count NT (wave-uniform), so that its body is straight-line code:
-  // all NT x 8 score MFMAs first, then a branch-free soft-max over the NT tiles (the scale folded into the
-  // exponent's fma, row maxima by VALU lane swaps, row sums kept as per-lane partials), then the PV MFMAs.  With
-  // one soft-max call per row tile the calls' branches kept the MFMA chains and the VALU work of different row
-  // tiles from overlapping, and the wave (alone on its SIMD) ran at the sum of every latency.
-  auto tile_loop = [&](auto nt_tag) {
-    constexpr int NT = decltype(nt_tag)::value;
-    for (int it = 0; it < n_iter; ++it) {
-      const int tt = t_begin + it * kTile;
-      const int buf = it & 1;
-      __syncthreads();  // buffer `buf` is complete; the loaders may now overwrite buffer buf ^ 1
-      long_tile_compute<NT, RT>(reinterpret_cast<const char*>(kv_lds[buf][0]), reinterpret_cast<const char*>(kv_lds[buf][1]),
-                                qf, row_ok, row_pos, m_run, l_run, o_acc, tt, t_end, ctx, q_len, scale_log2, g, c16);
-    }
-  };
-  if (my_tiles >= 3) {
-    tile_loop(std::integral_constant<int, 3>{});
-  } else if (my_tiles == 2) {
-    tile_loop(std::integral_constant<int, 2>{});
-  } else if (my_tiles == 1) {
-    tile_loop(std::integral_constant<int, 1>{});
-  } else {
-    for (int it = 0; it < n_iter; ++it) __syncthreads();  // an idle wave still meets the loaders' barriers
-  }
-
-  float l_tot[RT];  // the per-lane partial row sums of the four token groups, combined (all lanes take part)
-#pragma unroll
-  for (int mt = 0; mt < RT; ++mt) l_tot[mt] = rowgroup_sum(l_run[mt]);
-#pragma unroll
-  for (int mt = 0; mt < RT; ++mt) {
-    if (!row_ok[mt]) continue;
-    const int rr = row_base + (wave + 4 * mt) * 16 + c16;
-    const int pos = rr / G, gq = rr - pos * G;
-    const int64_t grow = static_cast<int64_t>(q0 + pos) * Hq + h * G + gq;
-    float* op = P.ws_o + (static_cast<int64_t>(blockIdx.y) * P.total_rows + grow) * kD + 4 * g;
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt)
-      *reinterpret_cast<float4*>(op + dt * 16) =
-          make_float4(o_acc[mt][dt][0] * out_scale, o_acc[mt][dt][1] * out_scale, o_acc[mt][dt][2] * out_scale,
-                      o_acc[mt][dt][3] * out_scale);
-    if (g == 0) {
-      float* mp = P.ws_ml + (static_cast<int64_t>(blockIdx.y) * P.total_rows + grow) * 2;
-      mp[0] = m_run[mt] * kLn2;
-      mp[1] = l_tot[mt];
-      if (blockIdx.y == 0) mark_unused_parts(P, grow);
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------------
-// Long-draft kernel for a bf16 cache, co-resident form.  Same work split as verify_attn_long_kernel (one kv
-// head and one token range per workgroup, wave w owns row tiles w, w+4, w+8, KV bytes read once for up to 192
-// rows) but FOUR waves and no loader waves: every VGPR allocation of a kernel is uniform, so the four loader
-// waves above held half of a CU's register file for nothing and a workgroup needed a whole empty CU -- beside
-// the short-request kernel (one 4-wave workgroup per CU) it could only start when that kernel drained, and the
-// "overlapped" pair ran back to back.  Here each wave moves its quarter of every K/V tile with LDS-DMA
-// (global_load_lds_dwordx4: no VGPR destination, 1 KiB per wave-instruction) into a ring of four 16 KiB tile
-// images, three tiles in flight, counted vmcnt + one raw s_barrier per tile; at <= 256 VGPRs and 64 KiB of LDS
-// a workgroup fits beside a short-request workgroup on the same CU and its MFMA / VALU work fills that
-// kernel's memory stalls.  The LDS image is the v_tile_off layout: the DMA writes lane-linear, so the row
+// Long-draft body (suffix drafts: up to 33 query positions = 132 rows at G = 4).  One kv head and one token
+// range per workgroup; wave w owns row tiles w, w+4, w+8 (up to 192 rows) against a 32-token K/V tile that is in
+// LDS once per workgroup, so the KV bytes of a long request are read once instead of once per 16-row group.
+// Four waves and NO loader waves.  Two earlier forms are what this one answers: (1) compute waves loading their
+// own tiles through registers ran at HBM latency per tile (hipcc drains vmcnt(0) at the loop head whenever a
+// register set is re-armed across the back edge); (2) four compute + four loader waves fixed that, but VGPR
+// allocation is per kernel, so the loader waves held half of a CU's register file for nothing and a workgroup
+// needed a whole EMPTY CU: beside the short-request kernel (one 4-wave workgroup per CU) it only started when
+// that kernel drained, and the "overlapped" pair ran back to back.  Here each wave moves its quarter of every
+// K/V tile with LDS-DMA (global_load_lds_dwordx4: no VGPR destination, 1 KiB per wave-instruction) into a ring
+// of four tile images, three tiles in flight, counted vmcnt + one raw s_barrier per tile; at <= 256 VGPRs and
+// 64 KiB of LDS a workgroup fits beside a short-request workgroup on the same CU and its MFMA / VALU work fills
+// that body's memory stalls.  The bf16 image is the v_tile_off layout: the DMA writes lane-linear, so the row
 // permutation and chunk swizzle are applied on the per-lane SOURCE address (cdna guide rule 21).
 // The loads are inline asm: hipcc does not count them, the s_waitcnt below are the only vmcnt waits in the
 // loop (the Q loads are drained before the first DMA is issued).
@@ -915,9 +722,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 constexpr int kLong4LdsU4 = kLongRing * 2 * kTile * 16;
 
 // Body of the co-resident long-draft kernel for workgroup (bx, by, bz); lds = kLong4LdsU4 uint4 of LDS.
+// KV8 (fp8 e4m3 cache): the DMA ring holds the raw bytes (4 slots x {K, V} x 4 KiB); every wave converts its
+// quarter of the NEXT tile into one of two bf16 images (v_tile_off layout, exact: every e4m3 value is a bf16 value)
+// while the current one is being consumed, so the compute code is the bf16 one and there is still one barrier per
+// tile.  k_scale folds into the soft-max scale, v_scale into the output.
+template <bool KV8>
 __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint4* lds, const int bx, const int by, const int bz) {
   constexpr int RT = kLongTilesPerWave;
-  uint4(*kv_lds)[2][kTile * 16] = reinterpret_cast<uint4(*)[2][kTile * 16]>(lds);  // [ring slot][K|V][32 tokens x 16 chunks]
+  // bf16: [ring slot][K|V][32 tokens x 16 chunks];  fp8: raw ring in the first half, the two bf16 images in the second
+  uint4(*kv_lds)[2][kTile * 16] = reinterpret_cast<uint4(*)[2][kTile * 16]>(KV8 ? lds + kLong4LdsU4 / 2 : lds);
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -945,7 +758,11 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
   const int last_group = (ctx - 1) & ~15;
 
   // ---- query rows of this wave ----
-  const float scale_log2 = P.sm_scale * kLog2e;
+  float scale_log2 = P.sm_scale * kLog2e, out_scale = 1.0f;
+  if (KV8) {
+    scale_log2 *= *P.k_scale;
+    out_scale = *P.v_scale;
+  }
   uint4 qf[RT][4];
   int row_pos[RT];
   bool row_ok[RT];
@@ -980,49 +797,97 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
   const int n_row_tiles = (min(n_rows - row_base, 4 * RT * 16) + 15) >> 4;
   const int my_tiles = __builtin_amdgcn_readfirstlane(n_row_tiles > wave ? (n_row_tiles - wave + 3) >> 2 : 0);
 
-  // ---- this wave's share of a tile: LDS rows 4 w .. 4 w + 3 and 16 + 4 w .. (1 KiB each) of K and of V ----
-  // LDS slot (row r, chunk slot c) holds chunk c ^ f(r) of token swap23(r)  (the inverse of v_tile_off)
-  const int r0 = 4 * wave + g;                                             // < 16: first page of the tile
-  const int tk = (r0 & ~12) | ((r0 & 4) << 1) | ((r0 & 8) >> 1);          // token of that row; row r0 + 16 -> tk + 16
-  const int ch = c16 ^ (((r0 & 3) << 2) | ((r0 >> 2) & 3));               // same for both rows
   const char* kc = reinterpret_cast<const char*>(P.k_cache);
   const char* vc = reinterpret_cast<const char*>(P.v_cache);
-  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<size_t>(
-      (__attribute__((address_space(3))) void*)(&kv_lds[0][0][0])));
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) void*)(lds)));
+  // ---- this wave's share of a tile ----
+  // bf16: LDS rows 4 w .. 4 w + 3 and 16 + 4 w .. (1 KiB each) of K and of V; LDS slot (row r, chunk slot c) holds
+  //       chunk c ^ f(r) of token swap23(r)  (the inverse of v_tile_off)
+  // fp8 : tokens 8 w .. 8 w + 7 (1 KiB of K, 1 KiB of V), raw and linear: lane = (token, 16-byte chunk)
+  const int r0 = 4 * wave + g;                                             // < 16: first page of the tile
+  const int tk = KV8 ? 8 * wave + (lane >> 3) : (r0 & ~12) | ((r0 & 4) << 1) | ((r0 & 8) >> 1);
+  const int ch = KV8 ? (lane & 7) : c16 ^ (((r0 & 3) << 2) | ((r0 >> 2) & 3));
   auto issue = [&](int jt) {
     const int tt = t_begin + jt * kTile;
-    const int f0 = min(tt, last_group), f1 = min(tt + 16, last_group);
-    const int64_t b0 = static_cast<int64_t>(btab[f0 / bs]) * P.block_stride + static_cast<int64_t>(f0 % bs) * kv_row + h * kD;
-    const int64_t b1 = static_cast<int64_t>(btab[f1 / bs]) * P.block_stride + static_cast<int64_t>(f1 % bs) * kv_row + h * kD;
-    const int64_t o0 = 2 * (b0 + static_cast<int64_t>(min(tt + tk, ctx - 1) - f0) * kv_row + 8 * ch);
-    const int64_t o1 = 2 * (b1 + static_cast<int64_t>(min(tt + 16 + tk, ctx - 1) - f1) * kv_row + 8 * ch);
-    const unsigned slot = lds0 + static_cast<unsigned>(jt & (kLongRing - 1)) * (2 * kTile * 256) + 1024 * wave;
-    glds16(kc + o0, slot);
-    glds16(kc + o1, slot + 4096);
-    glds16(vc + o0, slot + kTile * 256);
-    glds16(vc + o1, slot + kTile * 256 + 4096);
+    if constexpr (KV8) {
+      const int half = wave >> 1;   // tokens 0-15 / 16-31 of the tile: one page lookup per wave
+      const int f = min(tt + 16 * half, last_group);
+      const int64_t b = static_cast<int64_t>(btab[f / bs]) * P.block_stride + static_cast<int64_t>(f % bs) * kv_row + h * kD;
+      const int64_t o = b + static_cast<int64_t>(min(tt + tk, ctx - 1) - f) * kv_row + 16 * ch;
+      const unsigned slot = lds0 + static_cast<unsigned>(jt & (kLongRing - 1)) * (kTile * 256) + 1024 * wave;
+      glds16(kc + o, slot);
+      glds16(vc + o, slot + kTile * 128);
+    } else {
+      const int f0 = min(tt, last_group), f1 = min(tt + 16, last_group);
+      const int64_t b0 = static_cast<int64_t>(btab[f0 / bs]) * P.block_stride + static_cast<int64_t>(f0 % bs) * kv_row + h * kD;
+      const int64_t b1 = static_cast<int64_t>(btab[f1 / bs]) * P.block_stride + static_cast<int64_t>(f1 % bs) * kv_row + h * kD;
+      const int64_t o0 = 2 * (b0 + static_cast<int64_t>(min(tt + tk, ctx - 1) - f0) * kv_row + 8 * ch);
+      const int64_t o1 = 2 * (b1 + static_cast<int64_t>(min(tt + 16 + tk, ctx - 1) - f1) * kv_row + 8 * ch);
+      const unsigned slot = lds0 + static_cast<unsigned>(jt & (kLongRing - 1)) * (2 * kTile * 256) + 1024 * wave;
+      glds16(kc + o0, slot);
+      glds16(kc + o1, slot + 4096);
+      glds16(vc + o0, slot + kTile * 256);
+      glds16(vc + o1, slot + kTile * 256 + 4096);
+    }
   };
+  // fp8: this wave's quarter of raw tile jt -> bf16 image jt & 1
+  auto convert = [&](int jt) {
+    const char* raw = reinterpret_cast<const char*>(lds) + (jt & (kLongRing - 1)) * (kTile * 256) + 1024 * wave + 16 * lane;
+    const uint4 k8 = *reinterpret_cast<const uint4*>(raw);
+    const uint4 v8 = *reinterpret_cast<const uint4*>(raw + kTile * 128);
+    char* kb = reinterpret_cast<char*>(kv_lds[jt & 1][0]);
+    char* vb = reinterpret_cast<char*>(kv_lds[jt & 1][1]);
+    *reinterpret_cast<bf16x8*>(kb + v_tile_off(tk, 2 * ch)) = fp8x8_to_bf16x8(k8.x, k8.y);
+    *reinterpret_cast<bf16x8*>(kb + v_tile_off(tk, 2 * ch + 1)) = fp8x8_to_bf16x8(k8.z, k8.w);
+    *reinterpret_cast<bf16x8*>(vb + v_tile_off(tk, 2 * ch)) = fp8x8_to_bf16x8(v8.x, v8.y);
+    *reinterpret_cast<bf16x8*>(vb + v_tile_off(tk, 2 * ch + 1)) = fp8x8_to_bf16x8(v8.z, v8.w);
+  };
+  // wait until at most `tiles` of this wave's most recent tile loads are still in flight (DMAs retire in order)
+  auto wait_tiles = [&](int tiles) {
+    constexpr int per = KV8 ? 2 : 4;
+    if (tiles >= 3) {
+      if (per == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    } else if (tiles == 2) {
+      if (per == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (tiles == 1) {
+      if (per == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
+  constexpr int kAhead = KV8 ? kLongRing : kLongAhead;   // tiles issued before the loop
 #pragma unroll
-  for (int d = 0; d < kLongAhead; ++d)
+  for (int d = 0; d < kAhead; ++d)
     if (d < n_iter) issue(d);
+  if (KV8 && n_iter > 0) {
+    wait_tiles(min(n_iter, kAhead) - 1);
+    __builtin_amdgcn_s_barrier();   // tile 0 is in the ring
+    asm volatile("" ::: "memory");
+    convert(0);
+  }
 
   auto tile_loop = [&](auto nt_tag) {
     constexpr int NT = decltype(nt_tag)::value;
     for (int it = 0; it < n_iter; ++it) {
-      // tile `it` has landed when at most the tiles issued after it (4 DMAs each) are still outstanding
-      const int rem = n_iter - 1 - it;
-      if (rem >= 2) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      } else if (rem == 1) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if constexpr (KV8) {
+        // tile it + 1 must have landed (it is converted below); tiles it + 2, it + 3 may still be in flight
+        wait_tiles(min(2, max(0, n_iter - it - 2)));
+        __builtin_amdgcn_s_barrier();  // bf16 image of tile `it` complete; raw slot it & 3 and image (it + 1) & 1 are free
+        asm volatile("" ::: "memory");
+        if (it + kLongRing < n_iter) issue(it + kLongRing);
+        if (it + 1 < n_iter) convert(it + 1);
       } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // tile `it` has landed when at most the tiles issued after it are still outstanding
+        wait_tiles(min(2, n_iter - 1 - it));
+        __builtin_amdgcn_s_barrier();  // every wave's quarter of tile `it` is in LDS; ring slot (it - 1) & 3 is free
+        asm volatile("" ::: "memory");
+        if (it + kLongAhead < n_iter) issue(it + kLongAhead);
       }
-      __builtin_amdgcn_s_barrier();  // every wave's quarter of tile `it` is in LDS; ring slot (it - 1) & 3 is free
-      asm volatile("" ::: "memory");
-      if (it + kLongAhead < n_iter) issue(it + kLongAhead);
       if constexpr (NT > 0) {
-        const int slot = it & (kLongRing - 1);
+        const int slot = KV8 ? (it & 1) : (it & (kLongRing - 1));
         long_tile_compute<NT, RT>(reinterpret_cast<const char*>(kv_lds[slot][0]), reinterpret_cast<const char*>(kv_lds[slot][1]),
                                   qf, row_ok, row_pos, m_run, l_run, o_acc, t_begin + it * kTile, t_end, ctx, q_len,
                                   scale_log2, g, c16);
@@ -1052,7 +917,8 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt)
       *reinterpret_cast<float4*>(op + dt * 16) =
-          make_float4(o_acc[mt][dt][0], o_acc[mt][dt][1], o_acc[mt][dt][2], o_acc[mt][dt][3]);
+          make_float4(o_acc[mt][dt][0] * out_scale, o_acc[mt][dt][1] * out_scale, o_acc[mt][dt][2] * out_scale,
+                      o_acc[mt][dt][3] * out_scale);
     if (g == 0) {
       float* mp = P.ws_ml + (static_cast<int64_t>(by) * P.total_rows + grow) * 2;
       mp[0] = m_run[mt] * kLn2;
@@ -1062,9 +928,10 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
   }
 }
 
+template <bool KV8>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) verify_attn_long4_kernel(AttnParams P) {
   __shared__ uint4 lds[kLong4LdsU4];
-  verify_attn_long4_body(P, lds, blockIdx.x, blockIdx.y, blockIdx.z);
+  verify_attn_long4_body<KV8>(P, lds, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Short requests and long drafts of one call in ONE launch: workgroups [0, n_long_wg) run the long-draft body,
@@ -1073,7 +940,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 // workgroups still sit beside the short ones on the CUs (both bodies are 4 waves, <= 256 VGPRs, 64 KiB LDS: two
 // workgroups per CU), and they come first in the grid so that they are placed before the CUs fill up.
 // The long part is padded to a multiple of 8 workgroups (idle ones), which keeps the short body's XCD-aware item mapping.
-template <bool WH>
+template <bool WH, bool KV8>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 verify_attn_pair_kernel(AttnParams PS, AttnParams PL, int n_long_wg, int n_long_pad, int long_x, int long_y, int short_x) {
   __shared__ uint4 lds[kLong4LdsU4 > ShortLds<1, 4>::kU4 ? kLong4LdsU4 : ShortLds<1, 4>::kU4];
@@ -1082,10 +949,10 @@ verify_attn_pair_kernel(AttnParams PS, AttnParams PL, int n_long_wg, int n_long_
     if (b >= n_long_wg) return;
     const int x = b % long_x, yz = b / long_x;
     const int y = yz % long_y, z = yz / long_y;
-    verify_attn_long4_body(PL, lds, x, y, z);
+    verify_attn_long4_body<KV8>(PL, lds, x, y, z);
   } else {
     const int sb = b - n_long_pad;
-    verify_attn_body<1, WH, false, 4>(PS, lds, sb % short_x, sb / short_x);
+    verify_attn_body<1, WH, KV8, 4>(PS, lds, sb % short_x, sb / short_x);
   }
 }
 
@@ -1268,8 +1135,8 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   P.req_list = nullptr;
   P.k_scale = k_scale;
   P.v_scale = v_scale;
-  // tuning switches (every setting computes the same result): AIC_ATTN_DBG bit 2 (4) = 8-wave long-draft kernel for a
-  // bf16 cache too, bit 4 (16) = long then short on one stream, bit 5 (32) = two launches on two streams
+  // tuning switches (every setting computes the same result): AIC_ATTN_DBG bit 4 (16) = long then short on one
+  // stream, bit 5 (32) = two launches on two streams
   P.dbg = []() { const char* e = getenv("AIC_ATTN_DBG"); return e ? atoi(e) : 0; }();
 
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1306,7 +1173,7 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
     const int long_z = (max_rows + per_block_rows_p - 1) / per_block_rows_p;
     const int short_wg = (n_short * hgroups + 7) / 8 * 8 * n_splits;
     // one launch for both kinds of request when every workgroup of it can be resident at once (two per CU)
-    bool pair = n_short > 0 && n_long > 0 && !kv8 && !(P.dbg & (4 | 16 | 32));
+    bool pair = n_short > 0 && n_long > 0 && !(P.dbg & (16 | 32));
     if (pair) {
       const int room = 2 * 256 - short_wg;
       const int per_split = n_long * num_kv_heads * long_z;
@@ -1327,12 +1194,16 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
       const int n_long_wg = long_x * n_splits_long * long_z, n_long_pad = (n_long_wg + 7) / 8 * 8;
       const int short_x = (P.n_items + 7) / 8 * 8;
       profile_begin(s);
-      if (wave_heads)
-        hipLaunchKernelGGL(verify_attn_pair_kernel<true>, dim3(static_cast<unsigned>(n_long_pad + short_wg)), dim3(256), 0, s,
-                           P, PL, n_long_wg, n_long_pad, long_x, n_splits_long, short_x);
-      else
-        hipLaunchKernelGGL(verify_attn_pair_kernel<false>, dim3(static_cast<unsigned>(n_long_pad + short_wg)), dim3(256), 0, s,
-                           P, PL, n_long_wg, n_long_pad, long_x, n_splits_long, short_x);
+      const dim3 pgrid(static_cast<unsigned>(n_long_pad + short_wg));
+#define AIC_PAIR_LAUNCH(WH_, KV8_)                                                                              \
+  hipLaunchKernelGGL((verify_attn_pair_kernel<WH_, KV8_>), pgrid, dim3(256), 0, s, P, PL, n_long_wg, n_long_pad, long_x, \
+                     n_splits_long, short_x);
+      if (wave_heads) {
+        if (kv8) { AIC_PAIR_LAUNCH(true, true) } else { AIC_PAIR_LAUNCH(true, false) }
+      } else {
+        if (kv8) { AIC_PAIR_LAUNCH(false, true) } else { AIC_PAIR_LAUNCH(false, false) }
+      }
+#undef AIC_PAIR_LAUNCH
       profile_end(s);
       n_short = n_long = 0;  // both done
     }
@@ -1352,11 +1223,9 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
       PL.n_splits = n_splits_long;
       dim3 grid(static_cast<unsigned>(n_long * num_kv_heads), n_splits_long, (max_rows + per_block_rows - 1) / per_block_rows);
       if (kv8)
-        hipLaunchKernelGGL(verify_attn_long_kernel<true>, grid, dim3(512), 0, overlap ? side->stream : s, PL);
-      else if (P.dbg & 4)
-        hipLaunchKernelGGL(verify_attn_long_kernel<false>, grid, dim3(512), 0, overlap ? side->stream : s, PL);
+        hipLaunchKernelGGL(verify_attn_long4_kernel<true>, grid, dim3(256), 0, overlap ? side->stream : s, PL);
       else
-        hipLaunchKernelGGL(verify_attn_long4_kernel, grid, dim3(256), 0, overlap ? side->stream : s, PL);
+        hipLaunchKernelGGL(verify_attn_long4_kernel<false>, grid, dim3(256), 0, overlap ? side->stream : s, PL);
       if (overlap) AIC_HIP_TRY(hipEventRecord(side->join, side->stream));
       return AIC_OK;
     };
