@@ -16,6 +16,7 @@ host touches the step's results and runs while the host updates the suffix trees
 from __future__ import annotations
 
 from dataclasses import dataclass, field
+import itertools
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -231,22 +232,25 @@ class HotPathEngine:
         max_q, max_ctx = int(q_len.max()), int(ctx.max())
 
         # planted verify logits: row (request i, position p) gets the target's token for that position
-        truth = [next_truth(r, int(q_len[i])) for i, r in enumerate(reqs)]
-        plant_tok = np.concatenate([np.asarray(t, dtype=np.int64) for t in truth])
+        ql = q_len.tolist()
+        plant_tok = np.concatenate([next_truth(r, ql[i]) for i, r in enumerate(reqs)]).astype(np.int64, copy=False)
         # draft ids: suffix drafts are host lists; LSTM drafts of the previous step are still on the device (their
         # host copy is in flight and nobody waits for it here): placeholders now, filled on the device below
-        draft_flat = np.concatenate([np.asarray(r._drafts, dtype=np.int32) for r in reqs]) if n_draft.sum() else np.zeros(0, np.int32)
+        n_draft_total = int(n_draft.sum())
+        draft_flat = np.fromiter(itertools.chain.from_iterable(r._drafts for r in reqs), dtype=np.int32, count=n_draft_total)
         cu_draft = np.cumsum(n_draft)
-        fill_pos, fill_src = [], []
+        fill_pos = fill_src = np.zeros(0, np.int64)
         prev_lstm = getattr(self, "_lstm_prev", None)
         if prev_lstm is not None:
-            kcols = prev_lstm.shape[1]
-            for i, r in enumerate(reqs):
-                if r._pending is not None and not r._pending.done:
-                    k = int(n_draft[i])
-                    base = int(cu_draft[i]) - k
-                    fill_pos.extend(range(base, base + k))
-                    fill_src.extend(range(r.draft_row * kcols, r.draft_row * kcols + k))
+            pend_rows = np.fromiter((r.draft_row if (r._pending is not None and not r._pending.done) else -1 for r in reqs),
+                                    dtype=np.int64, count=B)
+            sel = np.nonzero(pend_rows >= 0)[0]
+            if len(sel):
+                k_sel = n_draft[sel].astype(np.int64)
+                rep = np.repeat(np.arange(len(sel)), k_sel)
+                within = np.arange(int(k_sel.sum())) - np.repeat(np.cumsum(k_sel) - k_sel, k_sel)
+                fill_pos = (cu_draft[sel] - k_sel)[rep] + within
+                fill_src = pend_rows[sel][rep] * prev_lstm.shape[1] + within
         # target rows = all but the last row of each request; bonus row = the last one (model_runner.py:394-404)
         is_bonus = np.zeros(T, dtype=bool)
         is_bonus[qsl[1:] - 1] = True
@@ -258,7 +262,7 @@ class HotPathEngine:
         G = self.hq_local // self.hkv_local
         so = ops.split_order(q_len, G)            # short / long request lists of the attention call
         parts = [ctx, qsl, draft_flat, cu_draft, plant_tok, target_rows, bonus_rows, np.asarray(live), slot_map,
-                 so[0] if so is not None else np.zeros(0, np.int32), np.asarray(fill_pos, np.int64), np.asarray(fill_src, np.int64)]
+                 so[0] if so is not None else np.zeros(0, np.int32), fill_pos, fill_src]
         kinds = [np.int32, np.int32, np.int32, np.int32, np.int64, np.int64, np.int64, np.int64, np.int64, np.int32,
                  np.int64, np.int64]
         offs, nbytes = [], 0
@@ -280,7 +284,7 @@ class HotPathEngine:
         d_seq, d_qsl, d_draft, d_cu = (dview(i, torch.int32) for i in range(4))
         d_plant, d_trows, d_brows, slots, d_slots = (dview(i, torch.int64) for i in range(4, 9))
         bt = self.block_table.index_select(0, slots) if B != self.max_num_seqs else self.block_table
-        if fill_pos:
+        if len(fill_pos):
             d_draft.index_copy_(0, dview(10, torch.int64), prev_lstm.reshape(-1).index_select(0, dview(11, torch.int64)).to(torch.int32))
 
         # (a) KV of the step's tokens for every layer in one launch (A16), then (b) verify attention per layer

@@ -76,6 +76,37 @@ def test_cache_surface_and_errors():
     assert c._prompt_tree("y").selfcheck() == 0
 
 
+def test_update_responses_equals_per_request_loop():
+    """The batched update (one native call) leaves every tree byte-identical to the per-request update_response loop
+    of the reference's _update_suffix_cache."""
+    import numpy as np
+    rng = random.Random(11)
+    a, b = SuffixCache(16), SuffixCache(16)
+    n = 24
+    prompts = [[rng.randrange(1, 9) for _ in range(rng.randint(5, 60))] for _ in range(n)]
+    for c in (a, b):
+        c.cache_prompts(list(range(n - 4)), prompts[:n - 4], n_threads=2)     # the last four have no prompt tree
+    for step in range(40):
+        runs = [[rng.randrange(1, 9) for _ in range(rng.choice([0, 1, 1, 2, 4, 9]))] for _ in range(n)]
+        for r in range(n):
+            if runs[r]:
+                a.update_response(r, runs[r])
+        live = [r for r in range(n) if runs[r] or step % 2]                    # zero-length runs are allowed
+        b.update_responses(live, np.asarray([t for r in live for t in runs[r]], dtype=np.int32),
+                           np.asarray([len(runs[r]) for r in live], dtype=np.int32))
+    def same(x, y):
+        ex, ey = x.export(), y.export()
+        assert ex.keys() == ey.keys()
+        for k in ex:
+            assert np.array_equal(np.asarray(ex[k]), np.asarray(ey[k])), k
+    same(a._global_tree(), b._global_tree())
+    for r in range(n - 4):
+        same(a._prompt_tree(r), b._prompt_tree(r))
+    assert b._global_tree().selfcheck() == 0
+    with pytest.raises(ValueError):
+        b.update_responses([0, 1], np.zeros(3, np.int32), np.asarray([1, 1], np.int32))
+
+
 def test_cache_tree_mode_matches_oracle():
     from oracle.suffix_oracle import OracleSuffixCache
     rng = random.Random(5)
