@@ -250,8 +250,11 @@ int aic_lstm_head(aic_lstm* m, int head_index, const int32_t* last_tokens /* [B]
  *     causal within the chunk.
  *       q/out: bf16 [T][Hq][D] (token stride q_stride / out_stride elements)
  *       block_table int32 [B][max_blocks]; seq_lens int32 [B] (context incl. the new tokens);
- *       query_start_loc int32 [B+1].  head_size 64 or 128.  kv_dtype BF16 or FP8_E4M3 (+ scales).
- *     workspace >= aic_verify_attention_workspace_bytes(...).  Graph-capture safe.
+ *       query_start_loc int32 [B+1].  head_size 128 (anything else: AIC_ERR_UNSUPPORTED); block_size a
+ *       multiple of 16.  kv_dtype BF16 or FP8_E4M3 (+ k_scale / v_scale device scalars).
+ *     workspace >= aic_verify_attention_workspace_bytes(...), private to the call until it completes on
+ *     `stream`.  Graph-capture safe.  Calls for one device come from one host thread at a time (the
+ *     fallback that runs long drafts on a library-owned side stream shares its fork/join events).
  * ---------------------------------------------------------------------------------------- */
 size_t aic_verify_attention_workspace_bytes(int num_tokens, int num_q_heads, int head_size, int num_splits_max);
 int aic_verify_attention(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
@@ -264,8 +267,10 @@ int aic_verify_attention(const void* q, int64_t q_stride, const void* k_cache, c
 /* Same, for callers that know the query lengths on the host (vLLM keeps num_scheduled_tokens there):
  * the batch is partitioned into `short_reqs` (device int32[n_short], requests with q_len * Hq/Hkv <= 16
  * query rows: one MFMA tile, KV streamed once) and `long_reqs` (device int32[n_long], e.g. 33-token suffix
- * drafts: a shared-tile kernel reads their KV once for up to 192 rows instead of once per 16-row group).
- * max_q_len bounds the long requests.  Lists NULL/0 -> identical to aic_verify_attention. */
+ * drafts: a shared-tile body reads their KV once for up to 192 rows instead of once per 16-row group).
+ * Both kinds run in ONE launch per call whenever all of its workgroups fit on the chip at once (<= 512;
+ * otherwise two launches, the long one on a side stream).  max_q_len bounds the long requests.
+ * Lists NULL/0 -> identical to aic_verify_attention. */
 int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
                             int64_t block_stride, int kv_dtype, const float* k_scale, const float* v_scale,
                             const int32_t* block_table, int max_blocks_per_seq, const int32_t* seq_lens,
