@@ -284,7 +284,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak",
+            "scaling": "strong",   # the global batch is fixed (64 live requests); N GPUs share it through SP / shift
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic",
