@@ -142,6 +142,17 @@ __device__ __forceinline__ void softmax_tile(const f32x4& s0, const f32x4& s1, b
   }
 }
 
+// Image of a 32-token tile for head size D: D = 128 is v_tile_off; D = 64 (128-byte rows, 8 chunks) XORs the chunk
+// with the row (the secondary head size: correct and DMA-fillable first, bank-optimal second).
+template <int D>
+__device__ __forceinline__ int tile_off(int t, int ch) {
+  if constexpr (D == 128) {
+    return v_tile_off(t, ch);
+  } else {
+    return 128 * t + 16 * (ch ^ (t & 7));
+  }
+}
+
 // Lanes c16 + 16 g (g = 0..3) hold the same query row.  gfx950's row / half swaps combine them on the VALU
 // (ds_bpermute costs an LDS round trip per step, and the long-draft kernel is VALU/latency bound).  The
 // s_nops are the VALU-write -> permlane-swap -> VALU-read hazards the assembler does not see inside asm.
@@ -592,17 +603,18 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((M
 // the PV MFMAs.  Straight-line code: with one soft-max call per row tile the calls' branches kept the MFMA
 // chains and the VALU work of different row tiles from overlapping, and the wave (alone on its SIMD) ran at the
 // sum of every latency.
-template <int NT, int RT>
-__device__ __forceinline__ void long_tile_compute(const char* kb, const char* vb, const uint4 (&qf)[RT][4],
+template <int NT, int RT, int D>
+__device__ __forceinline__ void long_tile_compute(const char* kb, const char* vb, const uint4 (&qf)[RT][D / 32],
                                                   const bool (&row_ok)[RT], const int (&row_pos)[RT],
-                                                  float (&m_run)[RT], float (&l_run)[RT], f32x4 (&o_acc)[RT][8], int tt,
+                                                  float (&m_run)[RT], float (&l_run)[RT], f32x4 (&o_acc)[RT][D / 16], int tt,
                                                   int t_end, int ctx, int q_len, float scale_log2, int g, int c16) {
     // K fragments of the tile (A operand of S^T = K Q^T): lane (token c16 [+16], d = 32 s + 8 g)
-    uint4 kf[2][4];
+    constexpr int DS = D / 32, DT = D / 16;   // k-steps of the score MFMAs, 16-wide output tiles
+    uint4 kf[2][DS];
 #pragma unroll
     for (int th = 0; th < 2; ++th)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) kf[th][s] = *reinterpret_cast<const uint4*>(kb + v_tile_off(16 * th + c16, 4 * s + g));
+      for (int s = 0; s < DS; ++s) kf[th][s] = *reinterpret_cast<const uint4*>(kb + tile_off<D>(16 * th + c16, 4 * s + g));
 
     f32x4 st[NT][2];
 #pragma unroll
@@ -610,7 +622,7 @@ __device__ __forceinline__ void long_tile_compute(const char* kb, const char* vb
 #pragma unroll
       for (int th = 0; th < 2; ++th) st[mt][th] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < DS; ++s)
 #pragma unroll
       for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
@@ -666,13 +678,13 @@ __device__ __forceinline__ void long_tile_compute(const char* kb, const char* vb
 #pragma unroll
       for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) o_acc[mt][dt] *= alpha[mt];
+        for (int dt = 0; dt < DT; ++dt) o_acc[mt][dt] *= alpha[mt];
     }
     const int q4 = c16 >> 2, p4 = c16 & 3;
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
-      const char* a_lo = vb + v_tile_off(4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
-      const char* a_hi = vb + v_tile_off(16 + 4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
+    for (int dt = 0; dt < DT; ++dt) {
+      const char* a_lo = vb + tile_off<D>(4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
+      const char* a_hi = vb + tile_off<D>(16 + 4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
           (s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(a_lo)));
       const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -723,14 +735,21 @@ constexpr int kLong4LdsU4 = kLongRing * 2 * kTile * 16;
 
 // Body of the co-resident long-draft kernel for workgroup (bx, by, bz); lds = kLong4LdsU4 uint4 of LDS.
 // KV8 (fp8 e4m3 cache): the DMA ring holds the raw bytes (4 slots x {K, V} x 4 KiB); every wave converts its
-// quarter of the NEXT tile into one of two bf16 images (v_tile_off layout, exact: every e4m3 value is a bf16 value)
+// quarter of the NEXT tile into one of two bf16 images (tile_off layout, exact: every e4m3 value is a bf16 value)
 // while the current one is being consumed, so the compute code is the bf16 one and there is still one barrier per
 // tile.  k_scale folds into the soft-max scale, v_scale into the output.
-template <bool KV8>
+// D = 64 (bf16 cache only): 128-byte rows, i.e. the DMA geometry of the fp8 case without the conversion; this body
+// then serves every request of a call (the hand-scheduled short body is D = 128 only).
+template <bool KV8, int D>
 __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint4* lds, const int bx, const int by, const int bz) {
+  static_assert(D == 128 || (D == 64 && !KV8), "head size 128, or 64 with a bf16 cache");
   constexpr int RT = kLongTilesPerWave;
-  // bf16: [ring slot][K|V][32 tokens x 16 chunks];  fp8: raw ring in the first half, the two bf16 images in the second
-  uint4(*kv_lds)[2][kTile * 16] = reinterpret_cast<uint4(*)[2][kTile * 16]>(KV8 ? lds + kLong4LdsU4 / 2 : lds);
+  constexpr int DS = D / 32, DT = D / 16;
+  constexpr bool ROW128 = KV8 || D == 64;          // a token row of the DMA source is 128 bytes (else 256)
+  constexpr int kImg = kTile * D * 2;              // bytes of one bf16 K (or V) image
+  constexpr int kImgBase = KV8 ? kLong4LdsU4 * 8 : 0;   // fp8: raw ring in the first half of the LDS, images behind it
+  constexpr int kRawSlot = kTile * 256;            // fp8 raw ring slot: K 4 KiB + V 4 KiB
+  char* const lds_b = reinterpret_cast<char*>(lds);
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -752,7 +771,7 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
   const int t_end = min(ctx, t_begin + tiles_per_part * kTile);
   const int n_iter = t_begin < t_end ? (t_end - t_begin + kTile - 1) / kTile : 0;
 
-  const int64_t kv_row = static_cast<int64_t>(Hkv) * kD;
+  const int64_t kv_row = static_cast<int64_t>(Hkv) * D;
   const_i32_ptr btab = (const_i32_ptr)(P.block_table + static_cast<int64_t>(req) * P.max_blocks);
   const int bs = P.block_size;
   const int last_group = (ctx - 1) & ~15;
@@ -763,7 +782,7 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
     scale_log2 *= *P.k_scale;
     out_scale = *P.v_scale;
   }
-  uint4 qf[RT][4];
+  uint4 qf[RT][DS];
   int row_pos[RT];
   bool row_ok[RT];
 #pragma unroll
@@ -773,26 +792,26 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
     const int rc = min(rr, n_rows - 1);
     const int pos = rc / G, gq = rc - pos * G;
     row_pos[mt] = pos;
-    const uint16_t* qp = P.q + static_cast<int64_t>(q0 + pos) * P.q_stride + static_cast<int64_t>(h * G + gq) * kD + 8 * g;
+    const uint16_t* qp = P.q + static_cast<int64_t>(q0 + pos) * P.q_stride + static_cast<int64_t>(h * G + gq) * D + 8 * g;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[mt][s] = *reinterpret_cast<const uint4*>(qp + 32 * s);
+    for (int s = 0; s < DS; ++s) qf[mt][s] = *reinterpret_cast<const uint4*>(qp + 32 * s);
   }
   // the Q loads are the only compiler-counted vector loads: retire them before any DMA is in flight, otherwise
   // hipcc's wait for them (vmcnt(0), placed at their first use INSIDE the loop) would drain the ring every tile
 #pragma unroll
   for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < DS; ++s)
       asm volatile("" : "+v"(qf[mt][s].x), "+v"(qf[mt][s].y), "+v"(qf[mt][s].z), "+v"(qf[mt][s].w));
 
   float m_run[RT], l_run[RT];
-  f32x4 o_acc[RT][8];
+  f32x4 o_acc[RT][DT];
 #pragma unroll
   for (int mt = 0; mt < RT; ++mt) {
     m_run[mt] = -INFINITY;
     l_run[mt] = 0.0f;
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) o_acc[mt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < DT; ++dt) o_acc[mt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int n_row_tiles = (min(n_rows - row_base, 4 * RT * 16) + 15) >> 4;
   const int my_tiles = __builtin_amdgcn_readfirstlane(n_row_tiles > wave ? (n_row_tiles - wave + 3) >> 2 : 0);
@@ -801,50 +820,52 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
   const char* vc = reinterpret_cast<const char*>(P.v_cache);
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) void*)(lds)));
   // ---- this wave's share of a tile ----
-  // bf16: LDS rows 4 w .. 4 w + 3 and 16 + 4 w .. (1 KiB each) of K and of V; LDS slot (row r, chunk slot c) holds
-  //       chunk c ^ f(r) of token swap23(r)  (the inverse of v_tile_off)
-  // fp8 : tokens 8 w .. 8 w + 7 (1 KiB of K, 1 KiB of V), raw and linear: lane = (token, 16-byte chunk)
+  // 256-byte rows (bf16, D = 128): LDS rows 4 w .. 4 w + 3 and 16 + 4 w .. (1 KiB each) of K and of V; LDS slot
+  //     (row r, chunk slot c) holds chunk c ^ f(r) of token swap23(r)  (the inverse of v_tile_off)
+  // 128-byte rows (fp8 raw bytes, or bf16 with D = 64): tokens 8 w .. 8 w + 7 (1 KiB of K, 1 KiB of V); lane =
+  //     (token, 16-byte chunk); the D = 64 image XORs the chunk with the row, fp8 raw bytes stay linear
   const int r0 = 4 * wave + g;                                             // < 16: first page of the tile
-  const int tk = KV8 ? 8 * wave + (lane >> 3) : (r0 & ~12) | ((r0 & 4) << 1) | ((r0 & 8) >> 1);
-  const int ch = KV8 ? (lane & 7) : c16 ^ (((r0 & 3) << 2) | ((r0 >> 2) & 3));
+  const int tk = ROW128 ? 8 * wave + (lane >> 3) : (r0 & ~12) | ((r0 & 4) << 1) | ((r0 & 8) >> 1);
+  const int ch = KV8 ? (lane & 7) : D == 64 ? ((lane & 7) ^ (tk & 7)) : c16 ^ (((r0 & 3) << 2) | ((r0 >> 2) & 3));
   auto issue = [&](int jt) {
     const int tt = t_begin + jt * kTile;
-    if constexpr (KV8) {
-      const int half = wave >> 1;   // tokens 0-15 / 16-31 of the tile: one page lookup per wave
+    if constexpr (ROW128) {
+      constexpr int EB = KV8 ? 1 : 2;   // bytes per cache element
+      const int half = wave >> 1;       // tokens 0-15 / 16-31 of the tile: one page lookup per wave
       const int f = min(tt + 16 * half, last_group);
-      const int64_t b = static_cast<int64_t>(btab[f / bs]) * P.block_stride + static_cast<int64_t>(f % bs) * kv_row + h * kD;
-      const int64_t o = b + static_cast<int64_t>(min(tt + tk, ctx - 1) - f) * kv_row + 16 * ch;
-      const unsigned slot = lds0 + static_cast<unsigned>(jt & (kLongRing - 1)) * (kTile * 256) + 1024 * wave;
+      const int64_t b = static_cast<int64_t>(btab[f / bs]) * P.block_stride + static_cast<int64_t>(f % bs) * kv_row + h * D;
+      const int64_t o = EB * (b + static_cast<int64_t>(min(tt + tk, ctx - 1) - f) * kv_row) + 16 * ch;
+      const unsigned slot = lds0 + static_cast<unsigned>(jt & (kLongRing - 1)) * kRawSlot + 1024 * wave;
       glds16(kc + o, slot);
-      glds16(vc + o, slot + kTile * 128);
+      glds16(vc + o, slot + kRawSlot / 2);
     } else {
       const int f0 = min(tt, last_group), f1 = min(tt + 16, last_group);
-      const int64_t b0 = static_cast<int64_t>(btab[f0 / bs]) * P.block_stride + static_cast<int64_t>(f0 % bs) * kv_row + h * kD;
-      const int64_t b1 = static_cast<int64_t>(btab[f1 / bs]) * P.block_stride + static_cast<int64_t>(f1 % bs) * kv_row + h * kD;
+      const int64_t b0 = static_cast<int64_t>(btab[f0 / bs]) * P.block_stride + static_cast<int64_t>(f0 % bs) * kv_row + h * D;
+      const int64_t b1 = static_cast<int64_t>(btab[f1 / bs]) * P.block_stride + static_cast<int64_t>(f1 % bs) * kv_row + h * D;
       const int64_t o0 = 2 * (b0 + static_cast<int64_t>(min(tt + tk, ctx - 1) - f0) * kv_row + 8 * ch);
       const int64_t o1 = 2 * (b1 + static_cast<int64_t>(min(tt + 16 + tk, ctx - 1) - f1) * kv_row + 8 * ch);
-      const unsigned slot = lds0 + static_cast<unsigned>(jt & (kLongRing - 1)) * (2 * kTile * 256) + 1024 * wave;
+      const unsigned slot = lds0 + static_cast<unsigned>(jt & (kLongRing - 1)) * (2 * kImg) + 1024 * wave;
       glds16(kc + o0, slot);
       glds16(kc + o1, slot + 4096);
-      glds16(vc + o0, slot + kTile * 256);
-      glds16(vc + o1, slot + kTile * 256 + 4096);
+      glds16(vc + o0, slot + kImg);
+      glds16(vc + o1, slot + kImg + 4096);
     }
   };
   // fp8: this wave's quarter of raw tile jt -> bf16 image jt & 1
   auto convert = [&](int jt) {
-    const char* raw = reinterpret_cast<const char*>(lds) + (jt & (kLongRing - 1)) * (kTile * 256) + 1024 * wave + 16 * lane;
+    const char* raw = lds_b + (jt & (kLongRing - 1)) * kRawSlot + 1024 * wave + 16 * lane;
     const uint4 k8 = *reinterpret_cast<const uint4*>(raw);
-    const uint4 v8 = *reinterpret_cast<const uint4*>(raw + kTile * 128);
-    char* kb = reinterpret_cast<char*>(kv_lds[jt & 1][0]);
-    char* vb = reinterpret_cast<char*>(kv_lds[jt & 1][1]);
-    *reinterpret_cast<bf16x8*>(kb + v_tile_off(tk, 2 * ch)) = fp8x8_to_bf16x8(k8.x, k8.y);
-    *reinterpret_cast<bf16x8*>(kb + v_tile_off(tk, 2 * ch + 1)) = fp8x8_to_bf16x8(k8.z, k8.w);
-    *reinterpret_cast<bf16x8*>(vb + v_tile_off(tk, 2 * ch)) = fp8x8_to_bf16x8(v8.x, v8.y);
-    *reinterpret_cast<bf16x8*>(vb + v_tile_off(tk, 2 * ch + 1)) = fp8x8_to_bf16x8(v8.z, v8.w);
+    const uint4 v8 = *reinterpret_cast<const uint4*>(raw + kRawSlot / 2);
+    char* kb = lds_b + kImgBase + (jt & 1) * (2 * kImg);
+    char* vb = kb + kImg;
+    *reinterpret_cast<bf16x8*>(kb + tile_off<D>(tk, 2 * ch)) = fp8x8_to_bf16x8(k8.x, k8.y);
+    *reinterpret_cast<bf16x8*>(kb + tile_off<D>(tk, 2 * ch + 1)) = fp8x8_to_bf16x8(k8.z, k8.w);
+    *reinterpret_cast<bf16x8*>(vb + tile_off<D>(tk, 2 * ch)) = fp8x8_to_bf16x8(v8.x, v8.y);
+    *reinterpret_cast<bf16x8*>(vb + tile_off<D>(tk, 2 * ch + 1)) = fp8x8_to_bf16x8(v8.z, v8.w);
   };
   // wait until at most `tiles` of this wave's most recent tile loads are still in flight (DMAs retire in order)
   auto wait_tiles = [&](int tiles) {
-    constexpr int per = KV8 ? 2 : 4;
+    constexpr int per = ROW128 ? 2 : 4;
     if (tiles >= 3) {
       if (per == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -888,9 +909,9 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
       }
       if constexpr (NT > 0) {
         const int slot = KV8 ? (it & 1) : (it & (kLongRing - 1));
-        long_tile_compute<NT, RT>(reinterpret_cast<const char*>(kv_lds[slot][0]), reinterpret_cast<const char*>(kv_lds[slot][1]),
-                                  qf, row_ok, row_pos, m_run, l_run, o_acc, t_begin + it * kTile, t_end, ctx, q_len,
-                                  scale_log2, g, c16);
+        const char* kb = lds_b + kImgBase + slot * (2 * kImg);
+        long_tile_compute<NT, RT, D>(kb, kb + kImg, qf, row_ok, row_pos, m_run, l_run, o_acc, t_begin + it * kTile, t_end,
+                                     ctx, q_len, scale_log2, g, c16);
       }
     }
   };
@@ -913,9 +934,9 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
     const int rr = row_base + (wave + 4 * mt) * 16 + c16;
     const int pos = rr / G, gq = rr - pos * G;
     const int64_t grow = static_cast<int64_t>(q0 + pos) * Hq + h * G + gq;
-    float* op = P.ws_o + (static_cast<int64_t>(by) * P.total_rows + grow) * kD + 4 * g;
+    float* op = P.ws_o + (static_cast<int64_t>(by) * P.total_rows + grow) * D + 4 * g;
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
       *reinterpret_cast<float4*>(op + dt * 16) =
           make_float4(o_acc[mt][dt][0] * out_scale, o_acc[mt][dt][1] * out_scale, o_acc[mt][dt][2] * out_scale,
                       o_acc[mt][dt][3] * out_scale);
@@ -928,10 +949,10 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
   }
 }
 
-template <bool KV8>
+template <bool KV8, int D = 128>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) verify_attn_long4_kernel(AttnParams P) {
   __shared__ uint4 lds[kLong4LdsU4];
-  verify_attn_long4_body<KV8>(P, lds, blockIdx.x, blockIdx.y, blockIdx.z);
+  verify_attn_long4_body<KV8, D>(P, lds, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Short requests and long drafts of one call in ONE launch: workgroups [0, n_long_wg) run the long-draft body,
@@ -949,7 +970,7 @@ verify_attn_pair_kernel(AttnParams PS, AttnParams PL, int n_long_wg, int n_long_
     if (b >= n_long_wg) return;
     const int x = b % long_x, yz = b / long_x;
     const int y = yz % long_y, z = yz / long_y;
-    verify_attn_long4_body<KV8>(PL, lds, x, y, z);
+    verify_attn_long4_body<KV8, 128>(PL, lds, x, y, z);
   } else {
     const int sb = b - n_long_pad;
     verify_attn_body<1, WH, KV8, 4>(PS, lds, sb % short_x, sb / short_x);
@@ -957,6 +978,7 @@ verify_attn_pair_kernel(AttnParams PS, AttnParams PL, int n_long_wg, int n_long_
 }
 
 // one wavefront per output row (token, q head): merge the n_parts partials
+template <int D>
 __global__ void __launch_bounds__(256)
 verify_attn_combine_kernel(const float* __restrict__ ws_o, const float* __restrict__ ws_ml, int n_parts, int total_rows,
                            int num_q_heads, uint16_t* __restrict__ out, int64_t out_stride) {
@@ -990,7 +1012,9 @@ verify_attn_combine_kernel(const float* __restrict__ ws_o, const float* __restri
       const int pj = p0 + j;
       w[j] = pj < n_parts ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w_l), pj & 63)) : 0.0f;
       const int pe = w[j] != 0.0f ? pj : p_ok;
-      o[j] = *reinterpret_cast<const float2*>(ws_o + (static_cast<int64_t>(pe) * total_rows + row) * kD + 2 * lane);
+      o[j] = make_float2(0.0f, 0.0f);
+      if (D == 128 || 2 * lane < D)   // D = 64: the upper half of the wave only takes part in the reductions
+        o[j] = *reinterpret_cast<const float2*>(ws_o + (static_cast<int64_t>(pe) * total_rows + row) * D + 2 * lane);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1001,9 +1025,9 @@ verify_attn_combine_kernel(const float* __restrict__ ws_o, const float* __restri
   const float inv = L > 0.0f ? 1.0f / L : 0.0f;
   if (!(L > 0.0f)) acc0 = acc1 = 0.0f;  // a row with nothing visible (cannot happen for a real token): zeros
   const int tok = row / num_q_heads, head = row - tok * num_q_heads;
-  uint16_t* op = out + static_cast<int64_t>(tok) * out_stride + static_cast<int64_t>(head) * kD + 2 * lane;
+  uint16_t* op = out + static_cast<int64_t>(tok) * out_stride + static_cast<int64_t>(head) * D + 2 * lane;
   const uint32_t packed = static_cast<uint32_t>(f32_to_bf16(acc0 * inv)) | (static_cast<uint32_t>(f32_to_bf16(acc1 * inv)) << 16);
-  *reinterpret_cast<uint32_t*>(op) = packed;
+  if (D == 128 || 2 * lane < D) *reinterpret_cast<uint32_t*>(op) = packed;
 }
 
 // Side stream for the long-draft kernel: a step's few long requests run beside the short-request kernel
@@ -1032,9 +1056,23 @@ static int side_stream(SideStream** out) {
 // (256 workgroups = one 4-wave workgroup per CU ran 190 us; 1152 workgroups = 1.5 rounds of 3 per CU 225 us),
 // and fewer splits also mean fewer partials to write and merge.  So: the smallest split count that gives every
 // CU a workgroup, rounded so the grid is a multiple of the CU count when the batch allows it.
+// compute units of the current device (256 on an MI355X in SPX mode; fewer in a partitioned mode)
+static int cu_count() {
+  static int cached = 0;
+  if (cached == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      cached = n;
+    else
+      cached = 256;
+  }
+  return cached;
+}
+
 static int pick_splits(int n_items, int max_seq_len, int min_tiles_per_split) {
   static const int64_t forced = []() { const char* e = getenv("AIC_ATTN_WAVES"); return e ? atoll(e) : 0LL; }();
-  constexpr int kCUs = 256;
+  const int kCUs = cu_count();
   const int max_tiles = (max_seq_len + kTile - 1) / kTile;
   int cap = std::max(1, max_tiles / std::max(1, min_tiles_per_split));
   if (cap > 64) cap = 64;
@@ -1082,8 +1120,12 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   AIC_REQUIRE(!split_lists || (n_short >= 0 && n_long >= 0 && n_short + n_long == batch &&
                                (n_short == 0 || short_reqs) && (n_long == 0 || long_reqs)),
               "short/long request lists must partition the batch");
-  if (head_size != kD) {
-    set_error("head_size %d not supported yet (128 only)", head_size);
+  if (head_size != kD && head_size != 64) {
+    set_error("head_size %d not supported (128, or 64 with a bf16 cache)", head_size);
+    return AIC_ERR_UNSUPPORTED;
+  }
+  if (head_size == 64 && kv_dtype != AIC_DT_BF16) {
+    set_error("head_size 64 needs a bf16 kv cache");
     return AIC_ERR_UNSUPPORTED;
   }
   if (kv_dtype != AIC_DT_BF16 && kv_dtype != AIC_DT_FP8_E4M3) {
@@ -1098,6 +1140,51 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
     return AIC_ERR_UNSUPPORTED;
   }
   AIC_NEED_DEVICE();
+
+  if (head_size == 64) {
+    // the secondary head size (gpt-oss): every request of the call takes the shared-tile body (one kv head and one
+    // token range per workgroup, up to 192 rows), whatever its query length; then the combine kernel
+    const size_t rows64 = static_cast<size_t>(num_tokens) * num_q_heads;
+    const int items = batch * num_kv_heads;
+    int splits = pick_splits(items, max_seq_len, 4);
+    auto fits64 = [&](int parts) { return static_cast<size_t>(parts) * rows64 * (64 + 2) * sizeof(float) <= workspace_bytes; };
+    while (splits > 1 && !fits64(splits)) --splits;
+    AIC_REQUIRE(fits64(splits), "workspace too small (%zu bytes)", workspace_bytes);
+    AttnParams P;
+    P.q = static_cast<const uint16_t*>(q);
+    P.k_cache = static_cast<const uint16_t*>(k_cache);
+    P.v_cache = static_cast<const uint16_t*>(v_cache);
+    P.block_table = block_table;
+    P.seq_lens = seq_lens;
+    P.query_start_loc = query_start_loc;
+    P.ws_o = static_cast<float*>(workspace);
+    P.ws_ml = P.ws_o + static_cast<size_t>(splits) * rows64 * 64;
+    P.q_stride = q_stride;
+    P.block_stride = block_stride;
+    P.max_blocks = max_blocks_per_seq;
+    P.num_q_heads = num_q_heads;
+    P.num_kv_heads = num_kv_heads;
+    P.block_size = block_size;
+    P.n_splits = splits;
+    P.n_parts_total = splits;
+    P.total_rows = static_cast<int>(rows64);
+    P.m_groups = 1;
+    P.n_items = items;
+    P.sm_scale = sm_scale;
+    P.req_list = nullptr;
+    P.k_scale = P.v_scale = nullptr;
+    P.dbg = 0;
+    hipStream_t s64 = static_cast<hipStream_t>(stream);
+    const int rows_per_wg = 4 * kLongTilesPerWave * 16;
+    const int max_rows64 = max_q_len * (num_q_heads / num_kv_heads);
+    dim3 grid(static_cast<unsigned>(items), static_cast<unsigned>(splits), static_cast<unsigned>((max_rows64 + rows_per_wg - 1) / rows_per_wg));
+    hipLaunchKernelGGL((verify_attn_long4_kernel<false, 64>), grid, dim3(256), 0, s64, P);
+    int rc64;
+    if ((rc64 = launch_status("verify_attn_long4_kernel<64>")) != AIC_OK) return rc64;
+    hipLaunchKernelGGL(verify_attn_combine_kernel<64>, dim3(static_cast<unsigned>((rows64 + 3) / 4)), dim3(256), 0, s64, P.ws_o,
+                       P.ws_ml, splits, static_cast<int>(rows64), num_q_heads, static_cast<uint16_t*>(out), out_stride);
+    return launch_status("verify_attn_combine_kernel<64>");
+  }
 
   const int G = num_q_heads / num_kv_heads;
   const int max_rows = max_q_len * G;
@@ -1175,7 +1262,7 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
     // one launch for both kinds of request when every workgroup of it can be resident at once (two per CU)
     bool pair = n_short > 0 && n_long > 0 && !(P.dbg & (16 | 32));
     if (pair) {
-      const int room = 2 * 256 - short_wg;
+      const int room = 2 * cu_count() - short_wg;
       const int per_split = n_long * num_kv_heads * long_z;
       if (room < per_split) {
         pair = false;
@@ -1254,7 +1341,7 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   }
 #undef AIC_ATTN_LAUNCH
   if ((rc = launch_status("verify_attn_kernel")) != AIC_OK) return rc;
-  hipLaunchKernelGGL(verify_attn_combine_kernel, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s, P.ws_o,
+  hipLaunchKernelGGL(verify_attn_combine_kernel<128>, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s, P.ws_o,
                      P.ws_ml, n_parts_total, static_cast<int>(rows), num_q_heads, static_cast<uint16_t*>(out), out_stride);
   return launch_status("verify_attn_combine_kernel");
 }

@@ -250,8 +250,9 @@ int aic_lstm_head(aic_lstm* m, int head_index, const int32_t* last_tokens /* [B]
  *     causal within the chunk.
  *       q/out: bf16 [T][Hq][D] (token stride q_stride / out_stride elements)
  *       block_table int32 [B][max_blocks]; seq_lens int32 [B] (context incl. the new tokens);
- *       query_start_loc int32 [B+1].  head_size 128 (anything else: AIC_ERR_UNSUPPORTED); block_size a
- *       multiple of 16.  kv_dtype BF16 or FP8_E4M3 (+ k_scale / v_scale device scalars).
+ *       query_start_loc int32 [B+1].  head_size 128, or 64 with a bf16 cache (anything else:
+ *       AIC_ERR_UNSUPPORTED); block_size a multiple of 16.  kv_dtype BF16 or FP8_E4M3 (+ k_scale / v_scale
+ *       device scalars).
  *     workspace >= aic_verify_attention_workspace_bytes(...), private to the call until it completes on
  *     `stream`.  Graph-capture safe.  Calls for one device come from one host thread at a time (the
  *     fallback that runs long drafts on a library-owned side stream shares its fork/join events).

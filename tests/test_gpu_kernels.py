@@ -250,6 +250,39 @@ def test_verify_attention_fp8_kv(cfg):
         assert torch.allclose(got.float().cpu(), want, atol=1e-3, rtol=2 ** -8), (extra, (got.float().cpu() - want).abs().max())
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(B=3, Hq=64, Hkv=8, q_lens=[4, 1, 3], ctxs=[300, 17, 1025], bs=16),          # gpt-oss heads (G = 8), k = 3 drafts
+    dict(B=4, Hq=8, Hkv=1, q_lens=[4, 33, 9, 2], ctxs=[1500, 2600, 130, 64], bs=16),  # its SP = 8 slice, suffix drafts
+    dict(B=2, Hq=16, Hkv=4, q_lens=[33, 20], ctxs=[700, 95], bs=32),                  # G = 4, block_size 32
+    dict(B=5, Hq=8, Hkv=8, q_lens=[1, 2, 1, 5, 1], ctxs=[1, 2, 33, 64, 4097], bs=16),  # G = 1; ctx == q_len; one-token contexts
+])
+def test_verify_attention_head_size_64(cfg):
+    """head_size 64 (gpt-oss-120b, BASELINE configs[4]): every request takes the shared-tile body."""
+    D = 64
+    q, kc, vc, bt, qsl = _attn_case(cfg["B"], cfg["Hq"], cfg["Hkv"], D, cfg["q_lens"], cfg["ctxs"], cfg["bs"], seed=13)
+    scale = 1.0 / D ** 0.5
+    want = O.verify_attention(q, kc, vc, bt, cfg["ctxs"], qsl, scale)
+    args = (q.to(DEV), kc.to(DEV), vc.to(DEV), bt.to(DEV), torch.tensor(cfg["ctxs"], dtype=torch.int32, device=DEV),
+            torch.tensor(qsl, device=DEV), max(cfg["q_lens"]), max(cfg["ctxs"]), scale)
+    for extra in ({}, {"q_lens_host": cfg["q_lens"]}):
+        got = _ops().verify_attention(*args, **extra)
+        assert torch.allclose(got.float().cpu(), want, atol=1e-3, rtol=2 ** -8), (extra, (got.float().cpu() - want).abs().max())
+
+
+def test_verify_attention_unsupported_shapes():
+    from arcticinference_amd._native import NativeError
+    q, kc, vc, bt, qsl = _attn_case(1, 4, 1, 96, [2], [40], 16, seed=1)
+    args = lambda q, kc, vc: (q.to(DEV), kc.to(DEV), vc.to(DEV), bt.to(DEV), torch.tensor([40], dtype=torch.int32, device=DEV),
+                              torch.tensor(qsl, device=DEV), 2, 40, 0.1)
+    with pytest.raises((NativeError, RuntimeError)):
+        _ops().verify_attention(*args(q, kc, vc))                       # head_size 96
+    q, kc, vc, bt, qsl = _attn_case(1, 4, 1, 64, [2], [40], 16, seed=1)
+    k8 = O.fp8_sat(kc.float(), "e4m3")
+    one = torch.ones(1, device=DEV)
+    with pytest.raises((NativeError, RuntimeError)):
+        _ops().verify_attention(*args(q, k8, k8), k_scale=one, v_scale=one)   # head_size 64 with an fp8 cache
+
+
 def test_verify_attention_strided_q_and_peaked_softmax():
     """q as a column slice of an all-to-all receive buffer; one key dominates (forces the online-softmax rescale)."""
     D, Hq, Hkv = 128, 8, 2

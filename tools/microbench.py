@@ -49,7 +49,7 @@ def attn(B=64, ctx=4096, qlen=4, Hq=32, Hkv=8, D=128, bs=16, layers=4, split=Fal
         ops.verify_attention(q, kv[0], kv[1], bt, seq, qsl, qlen, ctx, D ** -0.5, out=out, req_split=rs)
     us = timeit(f)
     gb = B * ctx * 2 * Hkv * D * 2 / 1e9
-    print(f"attn B={B} ctx={ctx} qlen={qlen} Hq={Hq} Hkv={Hkv}: {us:8.1f} us  {gb / us * 1e6 / 1e3:6.2f} TB/s (incl. combine)")
+    print(f"attn B={B} ctx={ctx} qlen={qlen} Hq={Hq} Hkv={Hkv} D={D}: {us:8.1f} us  {gb / us * 1e6 / 1e3:6.2f} TB/s (incl. combine)")
 
 
 def lstm(B, fp8=True):
@@ -89,6 +89,8 @@ if __name__ == "__main__":
         attn(B=16, qlen=33, split=True)
         attn(B=4, qlen=33, split=True)
         attn(B=1, qlen=33, split=True)
+        attn(B=64, Hq=64, Hkv=8, D=64)           # gpt-oss-120b heads (secondary head size: shared-tile body for all)
+        attn(B=64, Hq=8, Hkv=1, D=64)            # its SP = 8 slice
     if "long" in what:
         attn(B=16, qlen=33, split=True)
         attn(B=16, qlen=17, split=True)
