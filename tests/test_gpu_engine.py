@@ -11,10 +11,10 @@ from oracle.suffix_oracle import OracleSuffixCache
 pytestmark = pytest.mark.gpu
 
 
-def _build(method, with_lstm):
+def _build(method, with_lstm, head_size=128):
     from arcticinference_amd.engine import HotPathEngine, ModelShape, SpecConfig
     from arcticinference_amd.speculator import ArcticLSTMSpeculator, LSTMSpeculatorConfig, random_lstm_weights
-    shape = ModelShape(num_layers=2, num_q_heads=8, num_kv_heads=4, head_size=128, hidden_size=512, vocab_size=2000,
+    shape = ModelShape(num_layers=2, num_q_heads=8, num_kv_heads=4, head_size=head_size, hidden_size=512, vocab_size=2000,
                        block_size=16)
     spec = SpecConfig(method=method, num_speculative_tokens=3, enable_suffix_decoding=True)
     drafter = None
@@ -25,11 +25,11 @@ def _build(method, with_lstm):
     return HotPathEngine(shape, spec, 4, 400, drafter, device="cuda", seed=0), spec
 
 
-@pytest.mark.parametrize("method,with_lstm", [("suffix", False), ("arctic", True)])
-def test_engine_steps_match_oracle_policy(method, with_lstm):
+@pytest.mark.parametrize("method,with_lstm,head_size", [("suffix", False, 128), ("arctic", True, 128), ("arctic", True, 64)])
+def test_engine_steps_match_oracle_policy(method, with_lstm, head_size):
     from arcticinference_amd.workload import TokenSource
     from arcticinference_amd.vllm_plugin.runner_logic import MAX_SPEC_LEN
-    eng, spec = _build(method, with_lstm)
+    eng, spec = _build(method, with_lstm, head_size)
     src = TokenSource(vocab_size=2000, seed=3, n_motifs=3, motif_min=8, motif_max=16, p_motif=0.9)
     B, PL = 4, 96
     streams = {r: src.stream(PL + 200, r) for r in range(B)}
