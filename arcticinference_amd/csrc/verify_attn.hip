@@ -961,10 +961,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 // workgroups still sit beside the short ones on the CUs (both bodies are 4 waves, <= 256 VGPRs, 64 KiB LDS: two
 // workgroups per CU), and they come first in the grid so that they are placed before the CUs fill up.
 // The long part is padded to a multiple of 8 workgroups (idle ones), which keeps the short body's XCD-aware item mapping.
-template <bool WH, bool KV8>
+template <bool WH, bool KV8, int MTQ>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 verify_attn_pair_kernel(AttnParams PS, AttnParams PL, int n_long_wg, int n_long_pad, int long_x, int long_y, int short_x) {
-  __shared__ uint4 lds[kLong4LdsU4 > ShortLds<1, 4>::kU4 ? kLong4LdsU4 : ShortLds<1, 4>::kU4];
+  __shared__ uint4 lds[kLong4LdsU4 > ShortLds<MTQ, 4>::kU4 ? kLong4LdsU4 : ShortLds<MTQ, 4>::kU4];
   const int b = blockIdx.x;
   if (b < n_long_pad) {
     if (b >= n_long_wg) return;
@@ -973,7 +973,7 @@ verify_attn_pair_kernel(AttnParams PS, AttnParams PL, int n_long_wg, int n_long_
     verify_attn_long4_body<KV8, 128>(PL, lds, x, y, z);
   } else {
     const int sb = b - n_long_pad;
-    verify_attn_body<1, WH, KV8, 4>(PS, lds, sb % short_x, sb / short_x);
+    verify_attn_body<MTQ, WH, KV8, 4>(PS, lds, sb % short_x, sb / short_x);
   }
 }
 
@@ -1253,8 +1253,10 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
     }
     profile_end(s);
   } else {
-    // the caller partitioned the batch: `short_reqs` have q_len * G <= 16 rows (one MFMA tile, one pass),
-    // `long_reqs` go through the shared-tile kernel that reads their KV once for up to 192 rows
+    // the caller partitioned the batch: `short_reqs` have q_len * G <= 16 * mtq_short rows (one pass of the
+    // short body: one MFMA row tile when a k = 3 draft fits it, G <= 4, else two), `long_reqs` go through the
+    // shared-tile body that reads their KV once for up to 192 rows
+    const int mtq_short = 4 * G <= 16 ? 1 : 2;
     SideStream* side = nullptr;
     const int per_block_rows_p = 4 * kLongTilesPerWave * 16;
     const int long_z = (max_rows + per_block_rows_p - 1) / per_block_rows_p;
@@ -1283,8 +1285,12 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
       profile_begin(s);
       const dim3 pgrid(static_cast<unsigned>(n_long_pad + short_wg));
 #define AIC_PAIR_LAUNCH(WH_, KV8_)                                                                              \
-  hipLaunchKernelGGL((verify_attn_pair_kernel<WH_, KV8_>), pgrid, dim3(256), 0, s, P, PL, n_long_wg, n_long_pad, long_x, \
-                     n_splits_long, short_x);
+  if (mtq_short == 1)                                                                                           \
+    hipLaunchKernelGGL((verify_attn_pair_kernel<WH_, KV8_, 1>), pgrid, dim3(256), 0, s, P, PL, n_long_wg, n_long_pad, long_x, \
+                       n_splits_long, short_x);                                                                 \
+  else                                                                                                          \
+    hipLaunchKernelGGL((verify_attn_pair_kernel<WH_, KV8_, 2>), pgrid, dim3(256), 0, s, P, PL, n_long_wg, n_long_pad, long_x, \
+                       n_splits_long, short_x);
       if (wave_heads) {
         if (kv8) { AIC_PAIR_LAUNCH(true, true) } else { AIC_PAIR_LAUNCH(true, false) }
       } else {
@@ -1322,17 +1328,14 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
       P.m_groups = 1;
       P.n_items = n_short * hgroups;
       dim3 grid(static_cast<unsigned>((P.n_items + 7) / 8 * 8), n_splits, 1);
-      static const bool eight = []() { const char* e = getenv("AIC_ATTN_NW8"); return e && e[0] == '1'; }();
-      if (wave_heads && eight && !kv8 && num_kv_heads % 8 == 0) {
-        // experiment: 8 waves = 8 kv heads per workgroup -> whole 2 KiB token rows per workgroup
-        AttnParams P8 = P;
-        P8.n_items = n_short * (num_kv_heads / 8);
-        dim3 grid8(static_cast<unsigned>((P8.n_items + 7) / 8 * 8), n_splits, 1);
-        hipLaunchKernelGGL((verify_attn_kernel<1, true, false, 8>), grid8, dim3(512), 0, s, P8);
-      } else if (wave_heads) {
+      if (mtq_short == 1 && wave_heads) {
         AIC_ATTN_LAUNCH(1, true)
-      } else {
+      } else if (mtq_short == 1) {
         AIC_ATTN_LAUNCH(1, false)
+      } else if (wave_heads) {
+        AIC_ATTN_LAUNCH(2, true)
+      } else {
+        AIC_ATTN_LAUNCH(2, false)
       }
       profile_end(s);
     }

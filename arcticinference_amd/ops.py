@@ -184,10 +184,13 @@ def verify_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
 
 def split_order(q_lens_host: Sequence[int], group_size: int):
     """Host half of split_requests: (request ids with the short ones first, as int32; number of short requests), or
-    None when every request fits one 16-row MFMA tile (q_len * Hq/Hkv <= 16)."""
+    None when every request is short (q_len * Hq/Hkv <= 16 rows, or <= 32 rows when Hq/Hkv > 4)."""
     import numpy as np
     ql = np.asarray(q_lens_host)
-    is_short = ql * group_size <= 16
+    # the short body runs one 16-row MFMA tile per request when a k = 3 draft (4 positions) fits it (G <= 4),
+    # else two (G <= 8): same rule as aic_verify_attention_ex
+    short_rows = 16 if 4 * group_size <= 16 else 32
+    is_short = ql * group_size <= short_rows
     if is_short.all():
         return None
     order = np.concatenate([np.nonzero(is_short)[0], np.nonzero(~is_short)[0]]).astype(np.int32)
