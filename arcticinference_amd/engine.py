@@ -284,8 +284,6 @@ class HotPathEngine:
         d_seq, d_qsl, d_draft, d_cu = (dview(i, torch.int32) for i in range(4))
         d_plant, d_trows, d_brows, slots, d_slots = (dview(i, torch.int64) for i in range(4, 9))
         bt = self.block_table.index_select(0, slots) if B != self.max_num_seqs else self.block_table
-        if len(fill_pos):
-            d_draft.index_copy_(0, dview(10, torch.int64), prev_lstm.reshape(-1).index_select(0, dview(11, torch.int64)).to(torch.int32))
 
         # (a) KV of the step's tokens for every layer in one launch (A16), then (b) verify attention per layer
         self._write_kv(d_slots, T)
@@ -297,6 +295,10 @@ class HotPathEngine:
         self._stream = int(torch.cuda.current_stream().cuda_stream)   # looked up once per step, not once per layer
         self._attention_layers(T, bt, d_seq, d_qsl, max_q, max_ctx)
 
+        # the LSTM draft ids of the previous step (still on the device) go into this step's draft array; only the
+        # acceptance below reads it, so the fill is enqueued behind the attention launches, off the critical path
+        if len(fill_pos):
+            d_draft.index_copy_(0, dview(10, torch.int64), prev_lstm.reshape(-1).index_select(0, dview(11, torch.int64)).to(torch.int32))
         _mark('enqueue_attention')
         # (c) verify logits: plant, accept, un-plant
         lg = self.logits[:T]
