@@ -305,8 +305,13 @@ class HotPathEngine:
         col = d_plant.unsqueeze(1)
         saved = torch.gather(lg, 1, col)
         lg.scatter_(1, col, self._plant_col[:T])   # gather/scatter on device tensors only: nothing here may sync the stream
-        bonus = torch.argmax(lg.index_select(0, d_brows), dim=-1).to(torch.int32)  # vLLM's sampler on the bonus rows
-        tl = lg.index_select(0, d_trows) if len(target_rows) != T else lg
+        # gathered rows go to persistent buffers: a fresh [rows, V] tensor per step has a different size every step
+        # (suffix drafts vary) and sends the caching allocator to hipMalloc, which stalls host AND device for ms
+        if not hasattr(self, "_rows_buf"):
+            self._rows_buf = torch.empty(self.max_tokens, s.vocab_size, dtype=self.logits.dtype, device=dev)
+            self._bonus_buf = torch.empty(self.max_num_seqs, s.vocab_size, dtype=self.logits.dtype, device=dev)
+        bonus = torch.argmax(torch.index_select(lg, 0, d_brows, out=self._bonus_buf[:B]), dim=-1).to(torch.int32)  # vLLM's sampler on the bonus rows
+        tl = torch.index_select(lg, 0, d_trows, out=self._rows_buf[:len(target_rows)]) if len(target_rows) != T else lg
         max_spec = int(max(n_draft.max(), 1))
         rej = ops.rejection_sample(tl, d_draft, d_cu, bonus, max_spec)
         lg.scatter_(1, col, saved)
