@@ -92,13 +92,14 @@ logits_row_kernel(const T* __restrict__ logits, int64_t row_stride, int vocab, i
                   const int32_t* __restrict__ draft_ids, const int32_t* __restrict__ cu, int batch,
                   const float* __restrict__ temperature, const float* __restrict__ exp_noise,
                   float* __restrict__ part_val, int32_t* __restrict__ part_idx, float* __restrict__ stat_max,
-                  float* __restrict__ stat_sum, float* __restrict__ p_draft) {
+                  float* __restrict__ stat_sum, float* __restrict__ p_draft, const int64_t* __restrict__ row_index) {
   constexpr int V = Elem<T>::kVec;
   const int row = blockIdx.x;
   const int seg = blockIdx.y;
   const int begin = seg * seg_len;
   const int end = min(begin + seg_len, vocab);
-  const T* base = logits + static_cast<int64_t>(row) * row_stride;
+  // row r of the call lives at logits[row_index[r]] when the caller passes the un-gathered [T, V] logits
+  const T* base = logits + (row_index ? row_index[row] : static_cast<int64_t>(row)) * row_stride;
   __shared__ float s_v[4];
   __shared__ int s_i[4];
   __shared__ float s_m, s_z;
@@ -309,7 +310,7 @@ template <typename T>
 static int run_rejection(const void* logits, int64_t row_stride, int vocab, const int32_t* draft,
                          const int32_t* cu, const int32_t* bonus, const float* temperature, const double* uniform,
                          const float* noise, int batch, int rows, int max_spec_len, int32_t* out, int32_t* nacc,
-                         int32_t* last, int32_t* hidx, void* workspace, hipStream_t stream, bool random) {
+                         int32_t* last, int32_t* hidx, const int64_t* row_index, void* workspace, hipStream_t stream, bool random) {
   const int S = rows > 0 ? pick_splits(rows, vocab) : 1;  // a step without drafts still emits bonus tokens
   int seg_len = (vocab + S - 1) / S;
   seg_len = (seg_len + kSegQuantum - 1) / kSegQuantum * kSegQuantum;
@@ -327,11 +328,11 @@ static int run_rejection(const void* logits, int64_t row_stride, int vocab, cons
   if (vec_ok)                                                                                                     \
     hipLaunchKernelGGL((logits_row_kernel<T, MODE, true>), grid, dim3(256), 0, stream, lg, row_stride, vocab,     \
                        seg_len, n_splits, draft, cu, batch, temperature, noise, part_val, part_idx, stat_max,     \
-                       stat_sum, p_draft);                                                                        \
+                       stat_sum, p_draft, row_index);                                                             \
   else                                                                                                            \
     hipLaunchKernelGGL((logits_row_kernel<T, MODE, false>), grid, dim3(256), 0, stream, lg, row_stride, vocab,    \
                        seg_len, n_splits, draft, cu, batch, temperature, noise, part_val, part_idx, stat_max,     \
-                       stat_sum, p_draft);
+                       stat_sum, p_draft, row_index);
     if (!random) {
       AIC_ROW_LAUNCH(0)
     } else {
@@ -356,7 +357,7 @@ static int run_rejection(const void* logits, int64_t row_stride, int vocab, cons
 static int dispatch(const void* logits, int dtype, int64_t row_stride, int vocab, const int32_t* draft,
                     const int32_t* cu, const int32_t* bonus, const float* temperature, const double* uniform,
                     const float* noise, int batch, int rows, int max_spec_len, int32_t* out, int32_t* nacc,
-                    int32_t* last, int32_t* hidx, void* ws, void* stream, bool random) {
+                    int32_t* last, int32_t* hidx, const int64_t* row_index, void* ws, void* stream, bool random) {
   if (batch == 0) return AIC_OK;
   AIC_REQUIRE(cu && bonus && out && batch > 0 && rows >= 0 && vocab > 0, "bad arguments to rejection");
   AIC_REQUIRE(rows == 0 || (logits && draft && ws), "null logits / draft ids / workspace");
@@ -367,13 +368,13 @@ static int dispatch(const void* logits, int dtype, int64_t row_stride, int vocab
   switch (dtype) {
     case AIC_DT_F32:
       return run_rejection<float>(logits, row_stride, vocab, draft, cu, bonus, temperature, uniform, noise, batch,
-                                  rows, max_spec_len, out, nacc, last, hidx, ws, s, random);
+                                  rows, max_spec_len, out, nacc, last, hidx, row_index, ws, s, random);
     case AIC_DT_BF16:
       return run_rejection<bf16_t>(logits, row_stride, vocab, draft, cu, bonus, temperature, uniform, noise, batch,
-                                   rows, max_spec_len, out, nacc, last, hidx, ws, s, random);
+                                   rows, max_spec_len, out, nacc, last, hidx, row_index, ws, s, random);
     case AIC_DT_F16:
       return run_rejection<f16_t>(logits, row_stride, vocab, draft, cu, bonus, temperature, uniform, noise, batch,
-                                  rows, max_spec_len, out, nacc, last, hidx, ws, s, random);
+                                  rows, max_spec_len, out, nacc, last, hidx, row_index, ws, s, random);
     default:
       set_error("unsupported logits dtype %d", dtype);
       return AIC_ERR_UNSUPPORTED;
@@ -395,21 +396,22 @@ size_t aic_rejection_workspace_bytes(int num_draft_total, int vocab) {
 int aic_rejection_greedy(const void* target_logits, int logits_dtype, int64_t row_stride, int vocab,
                          const int32_t* draft_token_ids, const int32_t* cu_num_draft, const int32_t* bonus_token_ids,
                          int batch, int num_draft_total, int max_spec_len, int32_t* out_token_ids,
-                         int32_t* num_accepted, int32_t* last_token, int32_t* hidden_index, void* workspace,
-                         void* stream) {
+                         int32_t* num_accepted, int32_t* last_token, int32_t* hidden_index,
+                         const int64_t* target_row_index, void* workspace, void* stream) {
   return dispatch(target_logits, logits_dtype, row_stride, vocab, draft_token_ids, cu_num_draft, bonus_token_ids,
                   nullptr, nullptr, nullptr, batch, num_draft_total, max_spec_len, out_token_ids, num_accepted,
-                  last_token, hidden_index, workspace, stream, false);
+                  last_token, hidden_index, target_row_index, workspace, stream, false);
 }
 
 int aic_rejection_random(const void* target_logits, int logits_dtype, int64_t row_stride, int vocab,
                          const int32_t* draft_token_ids, const int32_t* cu_num_draft, const int32_t* bonus_token_ids,
                          const float* temperature, const double* uniform, const float* exp_noise, int batch,
                          int num_draft_total, int max_spec_len, int32_t* out_token_ids, int32_t* num_accepted,
-                         int32_t* last_token, int32_t* hidden_index, void* workspace, void* stream) {
+                         int32_t* last_token, int32_t* hidden_index, const int64_t* target_row_index, void* workspace,
+                         void* stream) {
   return dispatch(target_logits, logits_dtype, row_stride, vocab, draft_token_ids, cu_num_draft, bonus_token_ids,
                   temperature, uniform, exp_noise, batch, num_draft_total, max_spec_len, out_token_ids, num_accepted,
-                  last_token, hidden_index, workspace, stream, true);
+                  last_token, hidden_index, target_row_index, workspace, stream, true);
 }
 
 }  // extern "C"

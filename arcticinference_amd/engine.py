@@ -305,15 +305,13 @@ class HotPathEngine:
         col = d_plant.unsqueeze(1)
         saved = torch.gather(lg, 1, col)
         lg.scatter_(1, col, self._plant_col[:T])   # gather/scatter on device tensors only: nothing here may sync the stream
-        # gathered rows go to persistent buffers: a fresh [rows, V] tensor per step has a different size every step
-        # (suffix drafts vary) and sends the caching allocator to hipMalloc, which stalls host AND device for ms
-        if not hasattr(self, "_rows_buf"):
-            self._rows_buf = torch.empty(self.max_tokens, s.vocab_size, dtype=self.logits.dtype, device=dev)
+        # vLLM's sampler on the bonus rows (gathered into a persistent buffer: no per-step allocation); the target rows
+        # are read in place by the acceptance kernel through their row indices (target_logits_indices)
+        if not hasattr(self, "_bonus_buf"):
             self._bonus_buf = torch.empty(self.max_num_seqs, s.vocab_size, dtype=self.logits.dtype, device=dev)
-        bonus = torch.argmax(torch.index_select(lg, 0, d_brows, out=self._bonus_buf[:B]), dim=-1).to(torch.int32)  # vLLM's sampler on the bonus rows
-        tl = torch.index_select(lg, 0, d_trows, out=self._rows_buf[:len(target_rows)]) if len(target_rows) != T else lg
+        bonus = torch.argmax(torch.index_select(lg, 0, d_brows, out=self._bonus_buf[:B]), dim=-1).to(torch.int32)
         max_spec = int(max(n_draft.max(), 1))
-        rej = ops.rejection_sample(tl, d_draft, d_cu, bonus, max_spec)
+        rej = ops.rejection_sample(lg, d_draft, d_cu, bonus, max_spec, target_row_index=d_trows)
         lg.scatter_(1, col, saved)
 
         # (d) accepted tokens start their way to the host (pinned buffer, event) BEFORE the LSTM draft is

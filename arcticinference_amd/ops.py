@@ -113,11 +113,16 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 def rejection_sample(target_logits: torch.Tensor, draft_token_ids: torch.Tensor, cu_num_draft_tokens: torch.Tensor,
                      bonus_token_ids: torch.Tensor, max_spec_len: int, temperature: Optional[torch.Tensor] = None,
-                     uniform_probs: Optional[torch.Tensor] = None, exp_noise: Optional[torch.Tensor] = None
-                     ) -> RejectionResult:
+                     uniform_probs: Optional[torch.Tensor] = None, exp_noise: Optional[torch.Tensor] = None,
+                     target_row_index: Optional[torch.Tensor] = None) -> RejectionResult:
     """out[B, max_spec_len+1] int32 (-1 padded) as vLLM's RejectionSampler returns it for
-    draft_probs=None (call site model_runner.py:405-411), plus the proposer inputs of the next step."""
-    _need_cuda(target_logits, draft_token_ids, cu_num_draft_tokens, bonus_token_ids)
+    draft_probs=None (call site model_runner.py:405-411), plus the proposer inputs of the next step.
+    `target_row_index` (int64 [num_draft_total]): pass the model's full [T, V] logits as `target_logits` and the
+    rows to read (SpecDecodeMetadata.target_logits_indices) instead of a gathered copy."""
+    _need_cuda(target_logits, draft_token_ids, cu_num_draft_tokens, bonus_token_ids, target_row_index)
+    if target_row_index is not None and (target_row_index.dtype != torch.int64 or
+                                         target_row_index.numel() != draft_token_ids.numel()):
+        raise ValueError("target_row_index must be int64 with one entry per draft token")
     B = cu_num_draft_tokens.numel()
     rows = draft_token_ids.numel()
     V = target_logits.size(-1) if rows else 1
@@ -135,14 +140,15 @@ def rejection_sample(target_logits: torch.Tensor, draft_token_ids: torch.Tensor,
     if temperature is None:
         N.check(N.lib().aic_rejection_greedy(_ptr(target_logits) if rows else None, dt, stride, V, draft.data_ptr(),
                                              cu.data_ptr(), bonus.data_ptr(), B, rows, max_spec_len, out.data_ptr(),
-                                             nacc.data_ptr(), last.data_ptr(), hidx.data_ptr(), ws.data_ptr(),
-                                             N.current_stream_ptr()))
+                                             nacc.data_ptr(), last.data_ptr(), hidx.data_ptr(), _ptr(target_row_index),
+                                             ws.data_ptr(), N.current_stream_ptr()))
     else:
         N.check(N.lib().aic_rejection_random(_ptr(target_logits) if rows else None, dt, stride, V, draft.data_ptr(),
                                              cu.data_ptr(), bonus.data_ptr(), temperature.float().data_ptr(),
                                              uniform_probs.double().data_ptr(), exp_noise.float().data_ptr(), B, rows,
                                              max_spec_len, out.data_ptr(), nacc.data_ptr(), last.data_ptr(),
-                                             hidx.data_ptr(), ws.data_ptr(), N.current_stream_ptr()))
+                                             hidx.data_ptr(), _ptr(target_row_index), ws.data_ptr(),
+                                             N.current_stream_ptr()))
     return RejectionResult(out, nacc, last, hidx)
 
 

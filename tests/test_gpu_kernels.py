@@ -133,6 +133,16 @@ def test_rejection_greedy(B, V, max_n, dtype):
     assert np.array_equal(res.num_accepted.cpu().numpy(), nacc)
     last = want[np.arange(B), nacc - 1]
     assert np.array_equal(res.last_token.cpu().numpy(), last)
+    # the same rows read in place from a larger [T, V] tensor through target_row_index (target_logits_indices)
+    rows = logits.shape[0]
+    if rows:
+        pos = torch.randperm(rows + B, generator=torch.Generator().manual_seed(1))[:rows]
+        full = torch.randn(rows + B, V, generator=torch.Generator().manual_seed(2)).to(dtype)
+        full[pos] = logits
+        res2 = _ops().rejection_sample(full.to(DEV), torch.tensor(draft, dtype=torch.int32, device=DEV), cu,
+                                       torch.tensor(bonus, dtype=torch.int32, device=DEV), max_n,
+                                       target_row_index=pos.to(torch.int64).to(DEV))
+        assert np.array_equal(res2.output_token_ids.cpu().numpy(), want)
 
 
 def test_rejection_random_mixed():
