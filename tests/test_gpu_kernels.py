@@ -310,7 +310,8 @@ def test_verify_attention_strided_q_and_peaked_softmax():
     assert torch.allclose(got.float().cpu(), want, atol=1e-3, rtol=2 ** -8)
 
 
-def test_verify_attention_full_size_properties():
+@pytest.mark.parametrize("kv", ["bf16", "fp8"])
+def test_verify_attention_full_size_properties(kv):
     """BASELINE size (B=64, ~4096-token contexts, Llama-8B heads, k=3 and suffix-length drafts), where the fp32 oracle
     is too slow to be the checker: size-independent properties instead.
     (1) paging: physically shuffling the KV pages and permuting the block table must not change one bit;
@@ -331,6 +332,12 @@ def test_verify_attention_full_size_properties():
     kc = torch.randn(nb, bs, Hkv, D, device=DEV, dtype=torch.bfloat16)
     vc = torch.randn(nb, bs, Hkv, D, device=DEV, dtype=torch.bfloat16)
     v2 = torch.randn(nb, bs, Hkv, D, device=DEV, dtype=torch.bfloat16)
+    ks, vs = 1.0, 1.0
+    skw = {}
+    if kv == "fp8":   # the cache as the bulk KV op writes it: e4m3 codes of x / scale
+        ks, vs = 0.031, 0.017
+        kc, vc, v2 = (O.fp8_sat(t.float().cpu() / sc, "e4m3").to(DEV) for t, sc in ((kc, ks), (vc, vs), (v2, vs)))
+        skw = dict(k_scale=torch.tensor([ks], device=DEV), v_scale=torch.tensor([vs], device=DEV))
     T = sum(q_lens)
     q = torch.randn(T, Hq, D, device=DEV, dtype=torch.bfloat16)
     qsl = torch.tensor(np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32), device=DEV)
@@ -339,30 +346,33 @@ def test_verify_attention_full_size_properties():
     ops = _ops()
 
     def run(k, v, table, **kw):
-        return ops.verify_attention(q, k, v, table.to(DEV), seq, qsl, max(q_lens), max(ctxs), scale, **kw).float()
+        return ops.verify_attention(q, k, v, table.to(DEV), seq, qsl, max(q_lens), max(ctxs), scale, **skw, **kw).float()
 
     a = run(kc, vc, bt, q_lens_host=q_lens)
     # (1) shuffle the pages
     shuf = torch.randperm(nb)
     inv = torch.empty_like(shuf)
     inv[shuf] = torch.arange(nb)
-    a_shuf = run(kc[shuf.to(DEV)], vc[shuf.to(DEV)], inv[bt.long()].to(torch.int32), q_lens_host=q_lens)
+    def take(t, idx):   # page gather (through bytes: fp8 tensors have no index kernel)
+        return t.view(torch.uint8)[idx].view(t.dtype) if t.dtype not in (torch.bfloat16,) else t[idx]
+    a_shuf = run(take(kc, shuf.to(DEV)), take(vc, shuf.to(DEV)), inv[bt.long()].to(torch.int32), q_lens_host=q_lens)
     assert torch.equal(a, a_shuf)
     # (2) generic path
     b = run(kc, vc, bt)
     assert torch.allclose(a, b, atol=1e-3, rtol=2 ** -8), (a - b).abs().max()
     # (3) linearity in V (the V sum is formed in fp32 and rounded once: compare with matching slack)
-    a2 = run(kc, v2, bt, q_lens_host=q_lens)
-    vs = (vc.float() + v2.float()).to(torch.bfloat16)
-    a12 = run(kc, vs, bt, q_lens_host=q_lens)
-    assert torch.allclose(a12, a + a2, atol=6e-3, rtol=2 ** -6), (a12 - a - a2).abs().max()
+    if kv == "bf16":
+        a2 = run(kc, v2, bt, q_lens_host=q_lens)
+        vsum = (vc.float() + v2.float()).to(torch.bfloat16)
+        a12 = run(kc, vsum, bt, q_lens_host=q_lens)
+        assert torch.allclose(a12, a + a2, atol=6e-3, rtol=2 ** -6), (a12 - a - a2).abs().max()
     # (4) oracle on three requests (one of them a long draft)
     pick = [0, int(np.argmax(q_lens)), B - 1]
     qs = qsl.cpu().numpy()
     for i in pick:
         rows = slice(int(qs[i]), int(qs[i + 1]))
         want = O.verify_attention(q[rows].cpu(), kc.cpu(), vc.cpu(), bt[i:i + 1], [ctxs[i]],
-                                  np.array([0, q_lens[i]], dtype=np.int32), scale)
+                                  np.array([0, q_lens[i]], dtype=np.int32), scale, ks, vs)
         assert torch.allclose(a[rows].cpu(), want, atol=1e-3, rtol=2 ** -8), (i, (a[rows].cpu() - want).abs().max())
 
 
