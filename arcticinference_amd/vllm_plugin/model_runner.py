@@ -126,9 +126,13 @@ def build_model_runner_patch():
                     new_prompts.append(self.input_batch.token_ids_cpu[index, :n])
             if new_ids:
                 self._suffix_cache.cache_prompts(new_ids, new_prompts)          # trees built on host threads
-            for i, sampled in enumerate(sampled_token_ids):
-                if sampled:
-                    self._suffix_cache.update_response(self.input_batch.req_ids[i], sampled)
+            # the per-request update_response loop of the reference (:657-673) as one native call, same order
+            upd = [(self.input_batch.req_ids[i], sampled) for i, sampled in enumerate(sampled_token_ids) if sampled]
+            if upd:
+                import numpy as np
+                self._suffix_cache.update_responses(
+                    [r for r, _ in upd], np.fromiter((t for _, s in upd for t in s), dtype=np.int32),
+                    np.fromiter((len(s) for _, s in upd), dtype=np.int32, count=len(upd)))
             for req_id in self._suffix_cache.cached_prompt_ids():                # model_runner.py:675-678
                 if req_id not in seen:
                     self._suffix_cache.evict_prompt(req_id)
