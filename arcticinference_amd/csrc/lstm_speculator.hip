@@ -209,6 +209,12 @@ ln0_kernel(const uint16_t* __restrict__ hidden, const int32_t* __restrict__ hidd
 // (one set, one chunk ahead measured 2.6 TB/s).  The activation chunk (L2 resident) is copied one chunk
 // ahead into a double-buffered LDS tile shared by the four waves; one barrier per chunk.  The register
 // sets are named scalars: kept as arrays the compiler demotes them to scratch at this occupancy.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+__device__ __forceinline__ uint4 ld_stream16(const uint4* p) {
+  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 template <bool FP8, int MT, int EPI>
 __global__ void __launch_bounds__(256)
 skinny_gemm_kernel(const uint4* __restrict__ W, const uint4* __restrict__ X, int n_rowtiles, int steps_total,
@@ -237,13 +243,14 @@ skinny_gemm_kernel(const uint4* __restrict__ W, const uint4* __restrict__ X, int
   uint4 xr0, xr1, xr2, xr3;  // XV = MT <= 4 of them are live
   (void)xr1; (void)xr2; (void)xr3;
   uint4 a0_0, a0_1, a0_2, a0_3, a1_0, a1_1, a1_2, a1_3, a2_0, a2_1, a2_2, a2_3, a3_0, a3_1, a3_2, a3_3;
+  // weights are read once per launch (and the next launch's are long gone from the caches): non-temporal loads
 #define AIC_LOAD_A(set_, c_)                                              \
   {                                                                        \
     const uint4* p_ = a_ptr + static_cast<int64_t>(c_) * S * 64;           \
-    set_##_0 = p_[0];                                                      \
-    set_##_1 = p_[64];                                                     \
-    set_##_2 = p_[128];                                                    \
-    set_##_3 = p_[192];                                                    \
+    set_##_0 = ld_stream16(p_);                                            \
+    set_##_1 = ld_stream16(p_ + 64);                                       \
+    set_##_2 = ld_stream16(p_ + 128);                                      \
+    set_##_3 = ld_stream16(p_ + 192);                                      \
   }
 #define AIC_LOAD_X(c_)                                                        \
   {                                                                           \

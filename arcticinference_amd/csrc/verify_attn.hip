@@ -72,6 +72,15 @@ struct AttnParams {
   int dbg;
 };
 
+// 16-byte load of KV bytes, non-temporal: every byte of the cache is read once per call, and with the default
+// policy the stream evicts itself through the L2 (measured on the B = 64 x 4096-token case: 190.7 -> 171.0 us per
+// call, 5.63 -> 6.28 TB/s).
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+__device__ __forceinline__ uint4 ld_kv16(const char* p) {
+  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // Byte offset of 16-byte chunk `ch` (0..15) of token `t` (0..31) in the wave's V tile.  256-byte rows with
 // the chunk index XOR-ed by a function of the row (cdna guide T10, image (b)), and token groups 4-7 /
 // 8-11 swapped between rows so that the two 4-row blocks a 32-lane half reads transposed sit 8 rows
@@ -373,15 +382,15 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
     const int off1_ = min((tt_) + 16 + c16, ctx - 1) - (tp_).first1;                                           \
     const char* kp0_ = kc + ((tp_).base0 + static_cast<int64_t>(off0_) * kv_row) * ES + 16 * g;                \
     const char* kp1_ = kc + ((tp_).base1 + static_cast<int64_t>(off1_) * kv_row) * ES + 16 * g;                \
-    k00 = *reinterpret_cast<const uint4*>(kp0_);                                                               \
-    k01 = *reinterpret_cast<const uint4*>(kp0_ + 64);                                                          \
-    k10 = *reinterpret_cast<const uint4*>(kp1_);                                                               \
-    k11 = *reinterpret_cast<const uint4*>(kp1_ + 64);                                                          \
+    k00 = ld_kv16(kp0_);                                                               \
+    k01 = ld_kv16(kp0_ + 64);                                                          \
+    k10 = ld_kv16(kp1_);                                                               \
+    k11 = ld_kv16(kp1_ + 64);                                                          \
     if (!KV8) {                                                                                                \
-      k02 = *reinterpret_cast<const uint4*>(kp0_ + 128);                                                       \
-      k03 = *reinterpret_cast<const uint4*>(kp0_ + 192);                                                       \
-      k12 = *reinterpret_cast<const uint4*>(kp1_ + 128);                                                       \
-      k13 = *reinterpret_cast<const uint4*>(kp1_ + 192);                                                       \
+      k02 = ld_kv16(kp0_ + 128);                                                       \
+      k03 = ld_kv16(kp0_ + 192);                                                       \
+      k12 = ld_kv16(kp1_ + 128);                                                       \
+      k13 = ld_kv16(kp1_ + 192);                                                       \
     }                                                                                                          \
   }
   // bf16: instruction iv moves tokens 4 iv + g, 16-byte chunk c16;  fp8: tokens 8 iv + lane/8, chunk lane%8
@@ -392,15 +401,15 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
                static_cast<int64_t>(min((tt_) + 4 * (iv_) + g, ctx - 1) - ((iv_) >= 4 ? (tp_).first1 : (tp_).first0)) * kv_row) * 2 + 16 * c16)
 #define AIC_LOAD_V(tt_, tp_)                                                                                   \
   {                                                                                                            \
-    v0 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 0));                                             \
-    v1 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 1));                                             \
-    v2 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 2));                                             \
-    v3 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 3));                                             \
+    v0 = ld_kv16(AIC_V_ADDR(tt_, tp_, 0));                                             \
+    v1 = ld_kv16(AIC_V_ADDR(tt_, tp_, 1));                                             \
+    v2 = ld_kv16(AIC_V_ADDR(tt_, tp_, 2));                                             \
+    v3 = ld_kv16(AIC_V_ADDR(tt_, tp_, 3));                                             \
     if (!KV8) {                                                                                                \
-      v4 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 4));                                           \
-      v5 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 5));                                           \
-      v6 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 6));                                           \
-      v7 = *reinterpret_cast<const uint4*>(AIC_V_ADDR(tt_, tp_, 7));                                           \
+      v4 = ld_kv16(AIC_V_ADDR(tt_, tp_, 4));                                           \
+      v5 = ld_kv16(AIC_V_ADDR(tt_, tp_, 5));                                           \
+      v6 = ld_kv16(AIC_V_ADDR(tt_, tp_, 6));                                           \
+      v7 = ld_kv16(AIC_V_ADDR(tt_, tp_, 7));                                           \
     }                                                                                                          \
   }
 #define AIC_STORE_V(iv_, reg_)                                                                                  \
@@ -725,7 +734,7 @@ constexpr int kLongAhead = 3;  // tiles in flight
 
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
                : "v"(gsrc), "s"(lds_dst)
                : "memory");
