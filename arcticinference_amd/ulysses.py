@@ -148,36 +148,72 @@ class UlyssesAttention:
 
     `attn(q_, k_, v_)` receives strided views into the receive buffer: q_ [N, hq*D], k_/v_ [N, hkv*D] with
     row stride (hq + 2 hkv) * D, and returns [N, hq*D] contiguous.  `pack` / `unpack` default to the HIP
-    kernels; the CPU (gloo) tests inject torch expressions so the group / index logic runs without a GPU."""
+    kernels; the CPU (gloo) tests inject torch expressions so the group / index logic runs without a GPU.
+
+    KV-replicated variant (fewer kv heads than SP ranks, ulysses.py:437-451,462-490): every rank attends with ONE kv
+    head.  q takes the usual all-to-all over SP; K/V take an all-to-all inside the rank's SP_AA group (size = number of
+    kv heads: shards the heads) followed by an all-gather inside its SP_AG group (size SP / kv heads: collects the
+    tokens), and the gathered token chunks are put back into rank order.  Pass `kv_groups=(aa_group, aa_size,
+    ag_group, ag_size)`; the copies of this variant are torch expressions (decode-size tensors)."""
 
     def __init__(self, sp_size: int, group, num_q_heads_local: int, num_kv_heads_local: int, head_size: int,
-                 pack: Callable = _hip_pack, unpack: Callable = _hip_unpack, all_to_all: Optional[Callable] = None):
+                 pack: Callable = _hip_pack, unpack: Callable = _hip_unpack, all_to_all: Optional[Callable] = None,
+                 kv_groups: Optional[tuple] = None, all_gather: Optional[Callable] = None):
         self.sp_size, self.group = sp_size, group
         self.hq, self.hkv, self.D = num_q_heads_local, num_kv_heads_local, head_size
         self.pack, self.unpack = pack, unpack
-        # `all_to_all(recv, send)`: torch.distributed over the SP group unless a stand-in is injected (the
+        # `all_to_all(recv, send[, group])`: torch.distributed over the SP group unless a stand-in is injected (the
         # single-GPU shape rehearsal of bench.py --rehearse-sp copies send to recv)
         self._a2a = all_to_all
+        self._ag = all_gather
+        self.kv_groups = kv_groups
+        if kv_groups is not None:
+            _, aa, _, ag = kv_groups
+            assert aa * ag == sp_size and num_kv_heads_local == 1
+            # chunk c = j * aa + i of the gathered sequence holds the tokens of SP rank i * ag + j (ulysses.py:449-451)
+            self.order = [j * aa + i for i in range(aa) for j in range(ag)]
+
+    def _all_to_all(self, recv, send, group):
+        import torch.distributed as dist
+        if self._a2a is not None:
+            self._a2a(recv, send) if group is self.group else self._a2a(recv, send, group)
+        else:
+            dist.all_to_all_single(recv, send, group=group)
 
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, attn: Callable) -> torch.Tensor:
         import torch.distributed as dist
         if self.sp_size == 1:
             return attn(query, key, value)
         qw, kw = self.hq * self.D, self.hkv * self.D
-        send = self.pack(query, key, value, self.sp_size)               # [SP*n, qw + 2kw], rank-major
-        recv = torch.empty_like(send)
-        if self._a2a is not None:
-            self._a2a(recv, send)
+        if self.kv_groups is not None:
+            aa_group, aa, ag_group, ag = self.kv_groups
+            sp = self.sp_size
+            # q: all-to-all 1/2 over SP (ulysses.py:463-469)
+            q = query.view(-1, sp, qw).transpose(0, 1).reshape(-1, qw)
+            q_ = torch.empty_like(q)
+            self._all_to_all(q_, q, self.group)
+            # K/V: heads sharded inside SP_AA, tokens collected inside SP_AG, chunks back in rank order (:470-490)
+            kv = torch.cat((key.view(-1, aa, kw), value.view(-1, aa, kw)), dim=-1).transpose(0, 1).reshape(-1, 2 * kw)
+            kv_part = torch.empty_like(kv)
+            self._all_to_all(kv_part, kv, aa_group)
+            kv_ = torch.empty(q_.shape[0], 2 * kw, dtype=query.dtype, device=query.device)
+            if self._ag is not None:
+                self._ag(kv_, kv_part, ag_group)
+            else:
+                dist.all_gather_into_tensor(kv_, kv_part, group=ag_group)
+            chunks = kv_.chunk(sp)
+            kv_ordered = torch.cat([chunks[i] for i in self.order])
+            k_, v_ = kv_ordered.split([kw, kw], dim=-1)
+            c_ = attn(q_, k_, v_)
         else:
-            dist.all_to_all_single(recv, send, group=self.group)        # C1 (ulysses.py:502)
-        q_, k_, v_ = recv[:, :qw], recv[:, qw:qw + kw], recv[:, qw + kw:]
-        c_ = attn(q_, k_, v_)                                           # all N tokens, local heads
+            send = self.pack(query, key, value, self.sp_size)               # [SP*n, qw + 2kw], rank-major
+            recv = torch.empty_like(send)
+            self._all_to_all(recv, send, self.group)                        # C1 (ulysses.py:502)
+            q_, k_, v_ = recv[:, :qw], recv[:, qw:qw + kw], recv[:, qw + kw:]
+            c_ = attn(q_, k_, v_)                                           # all N tokens, local heads
         c = torch.empty_like(c_)
-        if self._a2a is not None:
-            self._a2a(c, c_)
-        else:
-            dist.all_to_all_single(c, c_, group=self.group)             # C2 (ulysses.py:514)
-        return self.unpack(c, self.sp_size)                             # [n, SP*qw]
+        self._all_to_all(c, c_, self.group)                                 # C2 (ulysses.py:514)
+        return self.unpack(c, self.sp_size)                                 # [n, SP*qw]
 
 
 class UlyssesContext:
@@ -195,10 +231,28 @@ class UlyssesContext:
         self.steps_sp = 0
         self.steps_shift = 0
         lh = local_heads(shape.num_q_heads, shape.num_kv_heads, sp_size)
-        if lh.kv_replicated:
-            raise NotImplementedError("KV-replicated Ulysses (Hkv < SP) is not on the MI355X path yet (SURVEY §8f-3)")
         self.heads = lh
-        self.attn = UlyssesAttention(sp_size, group, lh.num_q_heads, lh.num_kv_heads, shape.head_size, all_to_all=all_to_all)
+        kv_groups, all_gather = None, None
+        if lh.kv_replicated:
+            # fewer kv heads than ranks: SP = SP_AA (kv heads, all-to-all) x SP_AG (all-gather), ulysses.py:251-281
+            aa, ag = shape.num_kv_heads, sp_size // shape.num_kv_heads
+            aa_group = ag_group = None
+            if group is not None and all_to_all is None:
+                import torch.distributed as dist
+                g = rank_groups(sp_size, 1, 1, sp_size, 1, num_kv_heads=shape.num_kv_heads)
+                for ranks in g["SP_AA"]:          # every rank creates every group, in the same order
+                    h = dist.new_group(ranks)
+                    if sp_rank in ranks:
+                        aa_group = h
+                for ranks in g["SP_AG"]:
+                    h = dist.new_group(ranks)
+                    if sp_rank in ranks:
+                        ag_group = h
+            else:                                 # single-process rehearsal: the collectives are local copies
+                all_gather = lambda out, inp, _group: out.copy_(inp.repeat(ag, 1))
+            kv_groups = (aa_group, aa, ag_group, ag)
+        self.attn = UlyssesAttention(sp_size, group, lh.num_q_heads, lh.num_kv_heads, shape.head_size, all_to_all=all_to_all,
+                                     kv_groups=kv_groups, all_gather=all_gather)
 
     def attention_layers(self, eng, T, bt, d_seq, d_qsl, max_q, max_ctx) -> None:
         from . import ops
@@ -260,10 +314,14 @@ def build_ulysses_patches():
             sp = getattr(parallel_state, "_SP", None)
             self.sp_size = sp.world_size if sp is not None else 1
             self.sp_device_group = sp.device_group if sp is not None else None
+            self._kv_groups = None
             if self.sp_size > 1:
                 lh = local_heads(num_heads * 1, kwargs["num_kv_heads"], self.sp_size)
                 if lh.kv_replicated:
-                    raise NotImplementedError("KV-replicated Ulysses is not supported by this build")
+                    # fewer kv heads than SP ranks: the SP_AA / SP_AG groups of the parallel-state patch (:437-451)
+                    aa, ag = getattr(parallel_state, "_SP_AA", None), getattr(parallel_state, "_SP_AG", None)
+                    assert aa is not None and ag is not None, "KV-replicated Ulysses needs the SP_AA and SP_AG groups"
+                    self._kv_groups = (aa.device_group, aa.world_size, ag.device_group, ag.world_size)
                 num_heads //= self.sp_size
                 kwargs["num_kv_heads"] = lh.num_kv_heads
             return self._orig_init(num_heads, *args, **kwargs)
@@ -271,7 +329,8 @@ def build_ulysses_patches():
         def forward(self, query, key, value, **kwargs):
             if self.sp_size == 1:
                 return self._orig_forward(query, key, value, **kwargs)
-            ua = UlyssesAttention(self.sp_size, self.sp_device_group, self.num_heads, self.num_kv_heads, self.head_size)
+            ua = UlyssesAttention(self.sp_size, self.sp_device_group, self.num_heads, self.num_kv_heads, self.head_size,
+                                  kv_groups=self._kv_groups)
             return ua.forward(query, key, value, lambda q_, k_, v_: self._orig_forward(q_, k_, v_, **kwargs))
 
     return [UlyssesAttentionPatch]

@@ -92,3 +92,71 @@ def test_ulysses_attention_gloo(world, Hq, Hkv):
     assert sorted(r[0] for r in res) == list(range(world))
     assert all(r[1] for r in res), res
     assert all(r[2] == (8, Hq * 16) for r in res)
+
+
+def _worker_kv_replicated(rank, world, port, Hq, Hkv, D, N, out_q):
+    """Fewer kv heads than ranks (ulysses.py:437-451,462-490): q all-to-all over SP, K/V all-to-all inside SP_AA +
+    all-gather inside SP_AG + chunk reorder; every rank then attends with one kv head over all tokens."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from arcticinference_amd.ulysses import UlyssesAttention, local_heads, rank_groups
+        g = torch.Generator().manual_seed(1)
+        q = torch.randn(N, Hq * D, generator=g)
+        k = torch.randn(N, Hkv * D, generator=g)
+        v = torch.randn(N, Hkv * D, generator=g)
+        lh = local_heads(Hq, Hkv, world)
+        assert lh.kv_replicated and lh.num_kv_heads == 1
+        hq = lh.num_q_heads
+        aa, ag = Hkv, world // Hkv
+        groups = rank_groups(world, 1, 1, world, 1, num_kv_heads=Hkv)
+        aa_group = ag_group = None
+        for ranks in groups["SP_AA"]:
+            h = dist.new_group(ranks)
+            if rank in ranks:
+                aa_group = h
+        for ranks in groups["SP_AG"]:
+            h = dist.new_group(ranks)
+            if rank in ranks:
+                ag_group = h
+        n = N // world
+        sl = slice(rank * n, (rank + 1) * n)
+        seen = {}
+
+        def attn(q_, k_, v_):
+            assert q_.shape == (N, hq * D) and k_.shape == (N, D) and v_.shape == (N, D)
+            seen["k"] = k_.clone()
+            Q = q_.reshape(N, hq, D).transpose(0, 1)
+            K = k_.reshape(N, 1, D).transpose(0, 1).expand(hq, N, D)
+            V = v_.reshape(N, 1, D).transpose(0, 1).expand(hq, N, D)
+            s = Q @ K.transpose(1, 2) / D ** 0.5
+            s = s.masked_fill(~torch.tril(torch.ones(N, N, dtype=torch.bool)), float("-inf"))
+            return (torch.softmax(s, -1) @ V).transpose(0, 1).reshape(N, hq * D).contiguous()
+
+        ua = UlyssesAttention(world, dist.group.WORLD, hq, 1, D, unpack=lambda c, sp: O.ulysses_unpack(c, sp, hq, D),
+                              kv_groups=(aa_group, aa, ag_group, ag))
+        out = ua.forward(q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(), attn)
+        ref_all = _full(q, k, v, Hq, Hkv, D, N)
+        ok = torch.allclose(out, ref_all[sl], atol=1e-5)
+        # the rank saw ALL tokens, in order, of its one kv head (= rank // ag)
+        ok = ok and torch.equal(seen["k"], k.view(N, Hkv, D)[:, rank // ag])
+        out_q.put((rank, bool(ok), tuple(out.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ulysses_kv_replicated_gloo():
+    world, Hq, Hkv, D = 4, 8, 2, 16
+    ctx = mp.get_context("spawn")
+    qout = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_kv_replicated, args=(r, world, port, Hq, Hkv, D, 8 * world, qout)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [qout.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+    assert all(r[2] == (8, Hq * D) for r in res)
