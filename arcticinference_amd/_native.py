@@ -40,6 +40,11 @@ class LstmWeights(ctypes.Structure):
                 ("head_fp8", c_void_p), ("head_fp8_scale", c_float)]
 
 
+class MlpWeights(ctypes.Structure):
+    _fields_ = [("num_heads", c_int32), ("emb", c_void_p * 8), ("proj", c_void_p * 8), ("ln_w", c_void_p * 8),
+                ("ln_b", c_void_p * 8), ("head", c_void_p * 8)]
+
+
 def build(force: bool = False) -> str:
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     if force:
@@ -90,6 +95,7 @@ _SIGNATURES = {
                                      c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p]),
     "aic_lstm_create": (c_int, [POINTER(LstmConfig), POINTER(LstmWeights), POINTER(c_void_p)]),
+    "aic_mlp_create": (c_int, [POINTER(LstmConfig), POINTER(MlpWeights), POINTER(c_void_p)]),
     "aic_lstm_destroy": (None, [c_void_p]),
     "aic_quantize_fp8_per_tensor": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "aic_lstm_padding_size": (c_int, [c_int]),

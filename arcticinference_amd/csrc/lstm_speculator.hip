@@ -449,6 +449,53 @@ lstm_cell_kernel(const float* __restrict__ part, int n_splits, int m_pad, int ba
   if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(amax));
 }
 
+// ---- MLP speculator head (ArcticMLPSpeculator.generate_states, arctic_speculator.py:264-283): everything between
+// the projection and the LM head: states = proj(h) + (emb_weight / state_weight) z; states = gelu(ln(states)).
+// ln is MLPSpeculatorLayerNorm with scale and shift, evaluated in the tensor's dtype (bf16): r() at every op.
+__global__ void __launch_bounds__(1024)
+mlp_cell_kernel(const float* __restrict__ part, int n_splits, int m_pad, int batch, const int32_t* __restrict__ tokens,
+                const uint16_t* __restrict__ emb, int vocab_rows, float alpha, const uint16_t* __restrict__ ln_w,
+                const uint16_t* __restrict__ ln_b, int Ds, int MT, uint4* __restrict__ h_out,
+                unsigned int* __restrict__ amax_bits) {
+  extern __shared__ float smem[];  // [Ds]
+  __shared__ float sh[16];
+  const int m = blockIdx.x;
+  if (m >= batch) {
+    for (int k8 = threadIdx.x; k8 < Ds / 8; k8 += blockDim.x) h_out[xunit_bf16(m, k8, MT)] = make_uint4(0, 0, 0, 0);
+    return;
+  }
+  int tok = tokens[m];
+  if (tok < 0 || tok >= vocab_rows) tok = 0;
+  const uint16_t* z = emb + static_cast<int64_t>(tok) * Ds;
+  float ss = 0.0f;
+  for (int j = threadIdx.x; j < Ds; j += blockDim.x) {
+    float s = 0.0f;
+    for (int sp = 0; sp < n_splits; ++sp) s += part[(static_cast<int64_t>(sp) * m_pad + m) * Ds + j];
+    const float a = r(fmaf(alpha, bf16_to_f32(z[j]), r(s)));   // states.add_(z, alpha=...)
+    smem[j] = a;
+    ss += r(a * a);
+  }
+  ss = block_sum(ss, sh);
+  const float rs = r(rsqrtf(r(r(ss / static_cast<float>(Ds)) + 1e-6f)));
+  float amax = 0.0f;
+  for (int k8 = threadIdx.x; k8 < Ds / 8; k8 += blockDim.x) {
+    uint16_t h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int j = k8 * 8 + e;
+      float y = r(smem[j] * rs);
+      y = r(bf16_to_f32(ln_w[j]) * y);
+      y = r(y + bf16_to_f32(ln_b[j]));
+      const float st = r(gelu_erf(y));
+      h[e] = f32_to_bf16(st);
+      amax = fmaxf(amax, fabsf(st));
+    }
+    h_out[xunit_bf16(m, k8, MT)] = *reinterpret_cast<uint4*>(h);
+  }
+  for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+  if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(amax));
+}
+
 // ---- dynamic per-tensor activation quantisation for the fp8 LM head (fp8.py:303-308) ------------
 __global__ void __launch_bounds__(256)
 quant_act_kernel(const uint4* __restrict__ h_bf16, uint4* __restrict__ h_fp8, const unsigned int* __restrict__ amax_bits,
@@ -553,6 +600,17 @@ struct aic_lstm {
   float* x_scale = nullptr;
   int gate_splits = 2;
   int cur_mt = 0, cur_batch = 0;
+  // MLP speculator mode (aic_mlp_create): per-head tables; tied heads point at the same repacked copy
+  bool mlp = false;
+  int mlp_heads = 0;
+  uint4* mlp_proj_t[8] = {};
+  uint4* mlp_head_t[8] = {};
+  uint4* mlp_head8_t[8] = {};
+  float mlp_head8_scale[8] = {};
+  const uint16_t* mlp_emb[8] = {};
+  const uint16_t* mlp_ln_w[8] = {};
+  const uint16_t* mlp_ln_b[8] = {};
+  std::vector<void*> mlp_owned;
 };
 
 static int pad_mt(int batch) { return batch <= 16 ? 1 : (batch <= 32 ? 2 : 4); }
@@ -577,6 +635,42 @@ static int run_head(aic_lstm* m, int head_index, hipStream_t s, int64_t* out_tok
   const int mt = m->cur_mt, mpad = mt * 16, B = m->cur_batch;
   const int Ds = c.inner_dim;
   int rc;
+  if (m->mlp) {
+    AIC_REQUIRE(head_index < m->mlp_heads, "head %d of an MLP speculator with %d heads", head_index, m->mlp_heads);
+    // 1. projection (Ds x K), split-K partials in fp32;  2. + embedding, layer norm, gelu
+    const bool first = head_index == 0;
+    const int K = first ? c.input_hidden_dim : Ds;
+    const int steps_total = K / 32;
+    int splits = m->gate_splits;
+    while (splits > 1 && (steps_total % (splits * kChunkSteps) != 0)) --splits;
+    const int rowtiles = Ds / 16;
+    dim3 grid((rowtiles + 3) / 4, splits);
+    rc = launch_gemm<false, 0>(mt, grid, s, m->mlp_proj_t[head_index], first ? m->x0 : m->h_bf16, rowtiles, steps_total,
+                               steps_total / splits, m->part, Ds, nullptr, 1.0f, 0, 0, nullptr, nullptr);
+    if (rc != AIC_OK) return rc;
+    hipLaunchKernelGGL(mlp_cell_kernel, dim3(mpad), dim3(1024), Ds * sizeof(float), s, m->part, splits, mpad, B, m->tokens,
+                       m->mlp_emb[head_index], 0x7fffffff, m->alpha, m->mlp_ln_w[head_index], m->mlp_ln_b[head_index], Ds,
+                       mt, m->h_bf16, m->amax + head_index);
+    if ((rc = launch_status("mlp_cell_kernel")) != AIC_OK) return rc;
+    // 3. LM head + fused arg-max
+    const bool fp8m = m->mlp_head8_t[head_index] && mpad <= c.head_fp8_max_batch;
+    dim3 hgrid(m->head_blocks, 1);
+    if (fp8m) {
+      hipLaunchKernelGGL(quant_act_kernel, dim3(64), dim3(256), 0, s, m->h_bf16, m->h_fp8, m->amax + head_index,
+                         m->x_scale, Ds, mt);
+      if ((rc = launch_status("quant_act_kernel")) != AIC_OK) return rc;
+      rc = launch_gemm<true, 1>(mt, hgrid, s, m->mlp_head8_t[head_index], m->h_fp8, m->head_rowtiles, Ds / 64, Ds / 64,
+                                nullptr, 0, m->x_scale, m->mlp_head8_scale[head_index], c.vocab_size, c.vocab_offset,
+                                m->best_val, m->best_idx);
+    } else {
+      rc = launch_gemm<false, 1>(mt, hgrid, s, m->mlp_head_t[head_index], m->h_bf16, m->head_rowtiles, Ds / 32, Ds / 32,
+                                 nullptr, 0, nullptr, 1.0f, c.vocab_size, c.vocab_offset, m->best_val, m->best_idx);
+    }
+    if (rc != AIC_OK) return rc;
+    hipLaunchKernelGGL(argmax_finish_kernel, dim3(mpad), dim3(256), 0, s, m->best_val, m->best_idx, m->head_blocks, mpad,
+                       B, m->tokens, out_tokens, out_stride, out_col, out_vals);
+    return launch_status("argmax_finish_kernel");
+  }
   // 1. gate projection (4Ds x K), split-K partials in fp32
   {
     const bool first = head_index == 0;
@@ -716,11 +810,103 @@ int aic_lstm_create(const aic_lstm_config* cfg, const aic_lstm_weights* w, aic_l
   return AIC_OK;
 }
 
+// MLP speculator (arctic_speculator.py:102-401) on the same handle type and the same propose / begin / head entry
+// points.  Tied stages pass the same pointer for several heads; each distinct matrix is repacked once.
+int aic_mlp_create(const aic_lstm_config* cfg, const aic_mlp_weights* w, aic_lstm** out) {
+  AIC_REQUIRE(cfg && w && out, "null argument to aic_mlp_create");
+  AIC_REQUIRE(cfg->inner_dim > 0 && cfg->inner_dim % 512 == 0, "inner_dim must be a positive multiple of 512");
+  AIC_REQUIRE(cfg->input_hidden_dim > 0 && cfg->input_hidden_dim % 256 == 0,
+              "input_hidden_dim must be a positive multiple of 256");
+  AIC_REQUIRE(cfg->vocab_size > 0 && cfg->n_predict > 0 && cfg->max_batch > 0 && cfg->max_batch <= 64,
+              "vocab_size / n_predict must be positive and max_batch in 1..64");
+  AIC_REQUIRE(w->num_heads > 0 && w->num_heads <= 8, "an MLP speculator has 1..8 heads");
+  for (int i = 0; i < w->num_heads; ++i)
+    AIC_REQUIRE(w->emb[i] && w->proj[i] && w->ln_w[i] && w->ln_b[i] && w->head[i], "missing weight pointer of head %d", i);
+  AIC_NEED_DEVICE();
+  aic_lstm* m = new aic_lstm();
+  m->cfg = *cfg;
+  m->mlp = true;
+  m->mlp_heads = w->num_heads;
+  const int Ds = cfg->inner_dim, H = cfg->input_hidden_dim, V = cfg->vocab_size;
+  const double sw = std::pow(0.5, 0.5 / cfg->n_predict);                           // state_weight (:221)
+  const double ew = std::sqrt((1.0 - sw * sw) * (static_cast<double>(Ds) / 2.0));  // emb_weight (:222-223)
+  m->alpha = static_cast<float>(ew / sw);
+  m->head_blocks = (V + kRowsPerBlock - 1) / kRowsPerBlock;
+  m->head_rowtiles = m->head_blocks * 4;
+  m->max_mt = pad_mt(cfg->max_batch);
+  const int mpad = m->max_mt * 16;
+  const int Kmax = std::max(Ds, H);
+  hipStream_t s = nullptr;
+#define AIC_ALLOC(ptr, bytes) AIC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&(ptr)), (bytes)))
+  AIC_ALLOC(m->x0, static_cast<size_t>(mpad) * Kmax * 2);
+  AIC_ALLOC(m->h_bf16, static_cast<size_t>(mpad) * Kmax * 2);
+  AIC_ALLOC(m->h_fp8, static_cast<size_t>(mpad) * Ds);
+  AIC_ALLOC(m->cell, static_cast<size_t>(mpad) * Ds * 2);   // written by ln0_kernel, otherwise unused here
+  AIC_ALLOC(m->part, static_cast<size_t>(m->gate_splits) * mpad * Ds * 4);
+  AIC_ALLOC(m->best_val, static_cast<size_t>(m->head_blocks) * mpad * 4);
+  AIC_ALLOC(m->best_idx, static_cast<size_t>(m->head_blocks) * mpad * 4);
+  AIC_ALLOC(m->tokens, static_cast<size_t>(mpad) * 4);
+  AIC_ALLOC(m->amax, 64 * 4);
+  AIC_ALLOC(m->x_scale, 4);
+  int rc;
+  for (int i = 0; i < w->num_heads; ++i) {
+    m->mlp_emb[i] = static_cast<const uint16_t*>(w->emb[i]);
+    m->mlp_ln_w[i] = static_cast<const uint16_t*>(w->ln_w[i]);
+    m->mlp_ln_b[i] = static_cast<const uint16_t*>(w->ln_b[i]);
+    int same = -1;
+    for (int j = 1; j < i; ++j)   // head 0's projection has its own input width
+      if (w->proj[j] == w->proj[i]) same = j;
+    if (same >= 0) {
+      m->mlp_proj_t[i] = m->mlp_proj_t[same];
+    } else {
+      const int K = i == 0 ? H : Ds;
+      AIC_ALLOC(m->mlp_proj_t[i], static_cast<size_t>(Ds) * K * 2);
+      m->mlp_owned.push_back(m->mlp_proj_t[i]);
+      hipLaunchKernelGGL(repack_bf16_kernel, dim3(2048), dim3(256), 0, s, static_cast<const uint16_t*>(w->proj[i]),
+                         m->mlp_proj_t[i], Ds, K, Ds / 16);
+    }
+    same = -1;
+    for (int j = 0; j < i; ++j)
+      if (w->head[j] == w->head[i]) same = j;
+    if (same >= 0) {
+      m->mlp_head_t[i] = m->mlp_head_t[same];
+      m->mlp_head8_t[i] = m->mlp_head8_t[same];
+      m->mlp_head8_scale[i] = m->mlp_head8_scale[same];
+      continue;
+    }
+    AIC_ALLOC(m->mlp_head_t[i], static_cast<size_t>(m->head_rowtiles) * 16 * Ds * 2);
+    m->mlp_owned.push_back(m->mlp_head_t[i]);
+    hipLaunchKernelGGL(repack_bf16_kernel, dim3(4096), dim3(256), 0, s, static_cast<const uint16_t*>(w->head[i]),
+                       m->mlp_head_t[i], V, Ds, m->head_rowtiles);
+    if ((rc = launch_status("repack_bf16_kernel")) != AIC_OK) return rc;
+    if (cfg->head_fp8_max_batch > 0) {   // per-tensor e4m3 copy of the head, as the reference's qhead (:147-158)
+      AIC_ALLOC(m->mlp_head8_t[i], static_cast<size_t>(m->head_rowtiles) * 16 * Ds);
+      m->mlp_owned.push_back(m->mlp_head8_t[i]);
+      AIC_HIP_TRY(hipMemset(m->amax, 0, 4));
+      hipLaunchKernelGGL(amax_bf16_kernel, dim3(2048), dim3(256), 0, s, static_cast<const uint16_t*>(w->head[i]),
+                         static_cast<int64_t>(V) * Ds, m->amax);
+      hipLaunchKernelGGL(finish_scale_kernel, dim3(1), dim3(1), 0, s, m->amax, m->x_scale);
+      AIC_HIP_TRY(hipMemcpy(&m->mlp_head8_scale[i], m->x_scale, 4, hipMemcpyDeviceToHost));
+      hipLaunchKernelGGL(quant_repack_fp8_kernel, dim3(4096), dim3(256), 0, s, static_cast<const uint16_t*>(w->head[i]),
+                         m->mlp_head8_t[i], m->x_scale, V, Ds, m->head_rowtiles);
+      if ((rc = launch_status("quant_repack_fp8_kernel")) != AIC_OK) return rc;
+      AIC_HIP_TRY(hipDeviceSynchronize());   // x_scale is reused for the next head's scale
+    }
+  }
+#undef AIC_ALLOC
+  if ((rc = launch_status("repack_bf16_kernel")) != AIC_OK) return rc;
+  AIC_HIP_TRY(hipDeviceSynchronize());
+  *out = m;
+  return AIC_OK;
+}
+
 void aic_lstm_destroy(aic_lstm* m) {
   if (!m) return;
   void* bufs[] = {m->proj0_t, m->proj1_t, m->head_t, m->head8_t, m->x0,   m->h_bf16, m->h_fp8,
                   m->cell,    m->part,    m->best_val, m->best_idx, m->tokens, m->amax, m->x_scale};
   for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  for (void* b : m->mlp_owned)
     if (b) (void)hipFree(b);
   delete m;
 }

@@ -242,6 +242,139 @@ class ArcticLSTMSpeculator:
         return st["out"].view(-1)[: pad * k].view(pad, k)[:B].clone()
 
 
+@dataclass
+class MLPSpeculatorConfig:
+    """hf_config fields ArcticMLPSpeculator reads (arctic_speculator.py:115-122)."""
+    vocab_size: int
+    emb_dim: int                 # hidden size of the base model
+    inner_dim: int = 0           # 0 -> emb_dim (:118)
+    n_predict: int = 3
+    num_lookahead_tokens: int = 3
+    tie_weights: bool = False
+    scale_input: bool = False
+
+
+class ArcticMLPSpeculator(ArcticLSTMSpeculator):
+    """ArcticMLPSpeculator (arctic_speculator.py:102-401) on the same native kernels: per head a projection GEMM, one
+    fused add-embedding / layer-norm / gelu kernel and the LM-head GEMM with its arg-max.  Same public surface as the
+    LSTM speculator (generate_proposals, load_weights, the vocab-parallel begin / head_step / pick_global loop)."""
+
+    def __init__(self, config: MLPSpeculatorConfig, max_num_seqs: int = 64, tp_size: int = 1, tp_rank: int = 0,
+                 tp_group=None, device: str = "cuda", quantize_lm_head: bool = True, use_graph: bool = False):
+        self.config = config
+        self.n_predict = config.n_predict
+        self.vocab_size = config.vocab_size
+        self.input_hidden_dim = config.emb_dim
+        self.inner_dim = config.inner_dim if config.inner_dim != 0 else config.emb_dim
+        self.max_speculative_tokens = config.num_lookahead_tokens
+        self.tie_weights = config.tie_weights
+        if self.tie_weights:
+            assert self.n_predict > 1, "You cannot tie weights between stages when only 1 exists"
+        if self.max_speculative_tokens > 8:
+            raise NotImplementedError("at most 8 MLP speculator heads")
+        self.scale_input = config.scale_input
+        self.quantize_lm_head = quantize_lm_head
+        self.tp_size, self.tp_rank, self.tp_group = tp_size, tp_rank, tp_group
+        self.device = torch.device(device)
+        self.max_batch = min(64, padding_size(max_num_seqs))
+        self.use_graph = use_graph
+        self._graphs = {}
+        self.state_weight = 0.5 ** (0.5 / config.n_predict)
+        self.emb_weight = math.sqrt((1 - self.state_weight ** 2) * (self.inner_dim / 2))
+        padded = pad_vocab_size(self.vocab_size)
+        assert padded % tp_size == 0
+        self.shard_size = padded // tp_size
+        self.shard_start = tp_rank * self.shard_size
+        self.shard_rows = max(0, min(self.vocab_size, self.shard_start + self.shard_size) - self.shard_start)
+        self.weights = {}
+        self._h = None
+        self._static = None
+
+    def _stage(self, i: int, kind: str) -> int:
+        """Index of the parameter stage `i` uses: tied models keep one copy (proj: one for head 0, one for the rest)."""
+        if not self.tie_weights:
+            return i
+        return min(i, 1) if kind == "proj" else 0
+
+    def load_weights(self, weights: Iterable[Tuple[str, torch.Tensor]]):
+        """Name handling of the reference loader (arctic_speculator.py:392-401): `speculator.` prefix dropped, unknown
+        names ignored; a tied checkpoint needs emb.0 / proj.0 / proj.1 / ln.0 / head.0 only."""
+        w = collections.OrderedDict((k.replace("speculator.", ""), v) for k, v in weights)
+        Ds, H, k = self.inner_dim, self.input_hidden_dim, self.max_speculative_tokens
+        dev = self.device
+        bf = lambda t: t.to(device=dev, dtype=torch.bfloat16).contiguous()
+        cache: Dict[str, torch.Tensor] = {}
+
+        def take(name: str, shape, local_rows: bool = False) -> torch.Tensor:
+            if name not in cache:
+                if name not in w:
+                    raise KeyError(f"speculator checkpoint is missing '{name}'")
+                t = w[name]
+                assert tuple(t.shape) == tuple(shape), (name, tuple(t.shape), tuple(shape))
+                if local_rows:
+                    t = t[self.shard_start:self.shard_start + self.shard_rows]
+                cache[name] = bf(t)
+            return cache[name]
+
+        self.weights = {"emb": [], "proj": [], "ln_w": [], "ln_b": [], "head": []}
+        for i in range(k):
+            self.weights["emb"].append(take(f"emb.{self._stage(i, 'emb')}.weight", (self.vocab_size, Ds)))
+            self.weights["proj"].append(take(f"proj.{self._stage(i, 'proj')}.weight", (Ds, H if i == 0 else Ds)))
+            self.weights["ln_w"].append(take(f"ln.{self._stage(i, 'ln')}.weight", (Ds,)))
+            self.weights["ln_b"].append(take(f"ln.{self._stage(i, 'ln')}.bias", (Ds,)))
+            self.weights["head"].append(take(f"head.{self._stage(i, 'head')}.weight", (self.vocab_size, Ds), local_rows=True))
+        self._create_native()
+
+    def _create_native(self):
+        if self._h is not None:
+            N.lib().aic_lstm_destroy(self._h)
+        W = self.weights
+        k = self.max_speculative_tokens
+        cfg = N.LstmConfig(vocab_size=self.shard_rows, vocab_offset=self.shard_start,
+                           input_hidden_dim=self.input_hidden_dim, inner_dim=self.inner_dim,
+                           n_predict=self.n_predict, scale_input=int(self.scale_input), max_batch=self.max_batch,
+                           head_fp8_max_batch=32 if self.quantize_lm_head else 0)  # qhead when batch <= 32 (:299-300)
+        wt = N.MlpWeights()
+        wt.num_heads = k
+        for i in range(k):
+            wt.emb[i] = W["emb"][i].data_ptr()
+            wt.proj[i] = W["proj"][i].data_ptr()
+            wt.ln_w[i] = W["ln_w"][i].data_ptr()
+            wt.ln_b[i] = W["ln_b"][i].data_ptr()
+            wt.head[i] = W["head"][i].data_ptr()
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            N.check(N.lib().aic_mlp_create(ctypes.byref(cfg), ctypes.byref(wt), ctypes.byref(h)))
+        self._h = h
+        W["proj"] = W["head"] = None      # the library keeps fragment-major copies; embeddings and norms stay as they are
+        mb = self.max_batch
+        self._static = {
+            "hidden": torch.zeros(mb, self.input_hidden_dim, dtype=torch.bfloat16, device=self.device),
+            "tokens": torch.zeros(mb, dtype=torch.int32, device=self.device),
+            "out": torch.zeros(mb, self.max_speculative_tokens, dtype=torch.int64, device=self.device),
+            "vals": torch.zeros(mb, self.max_speculative_tokens, dtype=torch.float32, device=self.device),
+        }
+
+
+def random_mlp_weights(cfg: MLPSpeculatorConfig, seed: int = 0, std: float = 0.02
+                       ) -> "collections.OrderedDict[str, torch.Tensor]":
+    """Seeded synthetic MLP-speculator checkpoint with the reference's parameter names."""
+    g = torch.Generator().manual_seed(seed)
+    Ds = cfg.inner_dim if cfg.inner_dim != 0 else cfg.emb_dim
+    r = lambda *s: (torch.randn(*s, generator=g) * std).to(torch.bfloat16)
+    w = collections.OrderedDict()
+    k = cfg.num_lookahead_tokens
+    stages = range(1) if cfg.tie_weights else range(k)
+    for i in stages:
+        w[f"emb.{i}.weight"] = r(cfg.vocab_size, Ds)
+        w[f"head.{i}.weight"] = r(cfg.vocab_size, Ds)
+        w[f"ln.{i}.weight"] = (1.0 + 0.1 * torch.randn(Ds, generator=g)).to(torch.bfloat16)
+        w[f"ln.{i}.bias"] = (0.1 * torch.randn(Ds, generator=g)).to(torch.bfloat16)
+    for i in (range(2) if cfg.tie_weights else range(k)):
+        w[f"proj.{i}.weight"] = r(Ds, cfg.emb_dim if i == 0 else Ds)
+    return w
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 

@@ -62,6 +62,21 @@ def ArcticLSTMSpeculatorForVllm(*, vllm_config, prefix: str = ""):
                                 tp_rank=tp.rank % grp.world_size, tp_group=grp.device_group)
 
 
+def ArcticMLPSpeculatorForVllm(*, vllm_config, prefix: str = ""):
+    """Model-registry constructor with the reference's signature (arctic_speculator.py:112)."""
+    from ..speculator import ArcticMLPSpeculator, MLPSpeculatorConfig
+    hf = vllm_config.model_config.hf_config
+    cfg = MLPSpeculatorConfig(vocab_size=hf.vocab_size, emb_dim=hf.emb_dim, inner_dim=hf.inner_dim, n_predict=hf.n_predict,
+                              num_lookahead_tokens=hf.num_lookahead_tokens, tie_weights=hf.tie_weights,
+                              scale_input=hf.scale_input)
+    from vllm.distributed import parallel_state
+    sp = getattr(parallel_state, "_SP", None)
+    tp = parallel_state._TP
+    grp = sp if (sp is not None and sp.world_size > tp.world_size) else tp   # SpeculatorTPInit, vocab_parallel_embedding.py:20-35
+    return ArcticMLPSpeculator(cfg, max_num_seqs=vllm_config.scheduler_config.max_num_seqs, tp_size=grp.world_size,
+                               tp_rank=tp.rank % grp.world_size, tp_group=grp.device_group)
+
+
 def build_bootstrap_patches():
     """EngineCoreProc / WorkerBase patches that make the plugin load in every process (plugins.py:37-63)."""
     import vllm.plugins

@@ -36,6 +36,8 @@ def arctic_inference_plugin() -> None:
         raise RuntimeError("libarctic_hip.so found no HIP device; there is no CPU fallback")
 
     from vllm import ModelRegistry
+    ModelRegistry.register_model("ArcticMLPSpeculatorPreTrainedModel",
+                                 "arcticinference_amd.vllm_plugin.model_runner:ArcticMLPSpeculatorForVllm")
     ModelRegistry.register_model("ArcticLSTMSpeculatorPreTrainedModel",
                                  "arcticinference_amd.vllm_plugin.model_runner:ArcticLSTMSpeculatorForVllm")
     ModelRegistry.register_model("MLPVariantSpeculatorPreTrainedModel",

@@ -226,6 +226,21 @@ typedef struct aic_lstm_weights {
 } aic_lstm_weights;
 
 int aic_lstm_create(const aic_lstm_config* cfg, const aic_lstm_weights* w, aic_lstm** out);
+/* MLP speculator (ArcticMLPSpeculator, arctic_speculator.py:102-401): per head i
+ *   states = proj[i](h) + (emb_weight / state_weight) emb[i][tok];  h = gelu(ln[i](states));  tok = argmax(head[i] h)
+ * with ln = MLPSpeculatorLayerNorm (scale and shift), head 0 preceded by ln0(h)/sqrt(2) when scale_input.  The handle
+ * is used with the same propose / begin / head / destroy entry points as the LSTM one.  cfg->inner_dim is the model's
+ * inner_dim, cfg->input_hidden_dim its emb_dim.  With tie_weights pass the same pointers for the tied stages
+ * (proj[1..], emb, ln, head): every distinct matrix is re-laid out once. */
+typedef struct aic_mlp_weights {
+  int32_t num_heads;        /* max_speculative_tokens, <= 8 */
+  const void* emb[8];       /* bf16 [V_full, Ds] */
+  const void* proj[8];      /* bf16 [Ds, H] for head 0, [Ds, Ds] after */
+  const void* ln_w[8];      /* bf16 [Ds] */
+  const void* ln_b[8];      /* bf16 [Ds] */
+  const void* head[8];      /* bf16 [V_local, Ds] */
+} aic_mlp_weights;
+int aic_mlp_create(const aic_lstm_config* cfg, const aic_mlp_weights* w, aic_lstm** out);
 void aic_lstm_destroy(aic_lstm* m);
 /* per-tensor e4m3fn quantisation of a bf16 matrix: scale = amax/448, q = sat(x/scale)
  * (ops.scaled_fp8_quant with scale=None, fp8.py:207-210).  scale_out: device f32[1]. */

@@ -102,6 +102,42 @@ def lstm_generate_proposals(w: Dict[str, torch.Tensor], input_ids: torch.Tensor,
     return (toks, all_logits) if return_logits else toks
 
 
+def mlp_generate_proposals(w: Dict[str, torch.Tensor], input_ids: torch.Tensor, hidden: torch.Tensor, k: int,
+                           n_predict: int, inner_dim: int, tie_weights: bool, scale_input: bool = False,
+                           fp8_head: bool = False, return_logits: bool = False):
+    """ArcticMLPSpeculator.generate_states + generate_token_ids, tp_size == 1 (arctic_speculator.py:264-321), on CPU
+    bf16 with the module's parameter names (emb.i / proj.i / ln.i / head.i; tied models keep stage 0, proj 0 and 1)."""
+    dt = torch.bfloat16
+    state_weight = 0.5 ** (0.5 / n_predict)
+    emb_weight = math.sqrt((1 - state_weight ** 2) * (inner_dim / 2))
+    stage = (lambda i, kind: (min(i, 1) if kind == "proj" else 0)) if tie_weights else (lambda i, kind: i)
+    prev = hidden.to(dt).unsqueeze(1)          # b 1 d
+    last = input_ids.long().unsqueeze(1)       # b 1
+    gelu = torch.nn.GELU()
+    out, all_logits = [], []
+    for i in range(k):
+        if i == 0 and scale_input:
+            prev = _l2norm(prev) / SQRT2
+        z = torch.nn.functional.embedding(last, w[f"emb.{stage(i, 'emb')}.weight"].to(dt))
+        states = torch.nn.functional.linear(prev, w[f"proj.{stage(i, 'proj')}.weight"].to(dt))
+        states.add_(z, alpha=emb_weight / state_weight)
+        states = gelu(_l2norm(states, w[f"ln.{stage(i, 'ln')}.weight"].to(dt), w[f"ln.{stage(i, 'ln')}.bias"].to(dt)))
+        prev = states
+        flat = states.flatten(0, 1)
+        head_w = w[f"head.{stage(i, 'head')}.weight"].to(dt)
+        if fp8_head:
+            qw, w_scale = fp8_quant_per_tensor(head_w)
+            qx, x_scale = fp8_quant_per_tensor(flat)
+            logits = ((qx.to(torch.float32) @ qw.to(torch.float32).t()) * (x_scale * w_scale)).to(dt)
+        else:
+            logits = torch.nn.functional.linear(flat, head_w)
+        last = torch.argmax(logits, dim=-1).reshape(-1, 1)
+        out.append(last)
+        all_logits.append(logits)
+    toks = torch.cat(out, dim=-1)
+    return (toks, all_logits) if return_logits else toks
+
+
 def merge_lstm_checkpoint(ckpt: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """The reference loader's renaming (arctic_speculator.py:874-902) on a plain dict."""
     w = dict(ckpt)

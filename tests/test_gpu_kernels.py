@@ -434,6 +434,29 @@ def test_lstm_speculator_full_size():
     _check_tokens(got, want, logits, "full size")
 
 
+@pytest.mark.parametrize("B,tie,scale_input,fp8", [(3, False, False, False), (20, True, True, False), (64, False, True, False),
+                                                    (12, True, False, True)])
+def test_mlp_speculator(B, tie, scale_input, fp8):
+    """ArcticMLPSpeculator (arctic_speculator.py:102-401) against the CPU bf16 op-sequence oracle: tied and untied
+    stages, with and without the input norm, bf16 and fp8 LM head."""
+    from arcticinference_amd.speculator import ArcticMLPSpeculator, MLPSpeculatorConfig, random_mlp_weights
+    cfg = MLPSpeculatorConfig(vocab_size=3000, emb_dim=768, inner_dim=512, n_predict=3, num_lookahead_tokens=3,
+                              tie_weights=tie, scale_input=scale_input)
+    ck = random_mlp_weights(cfg, seed=2, std=0.05)
+    m = ArcticMLPSpeculator(cfg, max_num_seqs=64, device=DEV, quantize_lm_head=fp8)
+    m.load_weights(ck.items())
+    g = torch.Generator().manual_seed(B)
+    hidden = torch.randn(B, 768, generator=g).to(torch.bfloat16)
+    ids = torch.randint(0, 3000, (B,), generator=g)
+    use_fp8 = fp8 and (16 if B <= 16 else 32 if B <= 32 else 64) <= 32
+    want, logits = O.mlp_generate_proposals(ck, ids, hidden, 3, 3, 512, tie, scale_input, fp8_head=use_fp8, return_logits=True)
+    got = m.generate_proposals(ids.to(DEV), hidden.to(DEV), 3).cpu()
+    assert got.shape == (B, 3) and got.dtype == torch.int64
+    _check_tokens(got, want, logits, f"mlp B={B} tie={tie}", ulps=4 if use_fp8 else 1)
+    with pytest.raises(ValueError):
+        m.generate_proposals(ids.to(DEV), hidden.to(DEV), 4)
+
+
 def test_lstm_hidden_index_and_errors():
     from arcticinference_amd.speculator import ArcticLSTMSpeculator, LSTMSpeculatorConfig, random_lstm_weights
     cfg = LSTMSpeculatorConfig(vocab_size=1000, input_hidden_dim=512, inner_dim="512", emb_dim="512", proj_dim="512",
