@@ -183,3 +183,22 @@ def test_device_large_batch_of_queries():
         gu.assert_cand(res[r], gu.cand_dict(want), ctx=f"req {r}")
         hits += len(want.token_ids) > 0
     assert hits > 100
+
+
+def test_simulator_path_mode_matches_oracle_driver():
+    """The simulator with use_tree_spec=false (the HIP matcher) against the same driver on the oracle cache."""
+    import pandas as pd
+    from arcticinference_amd import simulator as S
+    from oracle.suffix_oracle import OracleSuffixCache
+    src = TokenSource(vocab_size=400, seed=12, n_motifs=6, motif_min=4, motif_max=10, p_motif=0.7)
+    rows = []
+    for r in range(16):
+        p, g = src.request(r, 64, 40)
+        rows.append({"prompt": [int(x) for x in p], "response": [int(x) for x in g]})
+    data = pd.DataFrame(rows)
+    cfg = dict(task_id=0, num_eval=6, num_train=9, seed=3, max_depth=32, max_spec_tokens=0, max_spec_factor=1.5,
+               min_token_prob=0.1, use_tree_spec=False, use_cached_prompt=True)
+    a = pd.DataFrame(S.run_task(SuffixCache, data, None, **cfg)).drop(columns=["spec_ms", "update_ms"])
+    b = pd.DataFrame(S.run_task(OracleSuffixCache, data, None, **cfg)).drop(columns=["spec_ms", "update_ms"])
+    assert a["num_accept_toks"].sum() > 0
+    pd.testing.assert_frame_equal(a, b)
