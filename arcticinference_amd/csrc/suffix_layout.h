@@ -12,7 +12,7 @@
 
 #include <cstdint>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define AIC_HD __host__ __device__
 #else
 #define AIC_HD
