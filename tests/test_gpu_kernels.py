@@ -217,6 +217,8 @@ def _attn_case(B, Hq, Hkv, D, q_lens, ctxs, bs, seed):
     dict(B=4, Hq=4, Hkv=1, q_lens=[4, 33, 9, 2], ctxs=[1500, 2600, 130, 64], bs=16),   # SP=8 slice with suffix drafts: short + long in one launch, waves = token ranges
     dict(B=3, Hq=16, Hkv=2, q_lens=[2, 20, 1], ctxs=[777, 1111, 48], bs=32),           # G = 8, two kv heads, one launch
     dict(B=40, Hq=32, Hkv=8, q_lens=[4] * 30 + [12, 33, 7, 20, 9, 33, 5, 16, 11, 6], ctxs=[260 + 37 * i for i in range(40)], bs=16),  # many items: the one-launch form does not fit, two launches
+    dict(B=3, Hq=32, Hkv=8, q_lens=[50, 4, 63], ctxs=[640, 64, 2049], bs=64),          # block_size 64; 200 and 252 rows: two 192-row groups
+    dict(B=2, Hq=8, Hkv=2, q_lens=[4, 1], ctxs=[128, 256], bs=128),                      # block_size 128, contexts at tile / page boundaries
 ])
 def test_verify_attention(cfg):
     D = 128
