@@ -187,7 +187,7 @@ class ArcticLSTMSpeculator:
                                              None, stream))
             return out
         # vocab-parallel: local (value, index) per head, one all-gather of 2B int64, arg-max over ranks
-        import torch.distributed as dist
+        from .dist_utils import all_gather_into_tensor
         self.begin(hs, hidx, B)
         outs = []
         last = toks
@@ -195,7 +195,7 @@ class ArcticLSTMSpeculator:
             tok_l, val_l = self.head_step(head, last, B)
             packed = torch.cat([val_l.to(torch.float64).view(torch.int64), tok_l])
             gathered = torch.empty(self.tp_size * 2 * B, dtype=torch.int64, device=self.device)
-            dist.all_gather_into_tensor(gathered, packed, group=self.tp_group)
+            all_gather_into_tensor(gathered, packed, group=self.tp_group)
             nxt = self.pick_global(gathered.view(self.tp_size, 2, B))
             outs.append(nxt.unsqueeze(1))
             last = nxt.to(torch.int32)

@@ -178,7 +178,8 @@ class UlyssesAttention:
         if self._a2a is not None:
             self._a2a(recv, send) if group is self.group else self._a2a(recv, send, group)
         else:
-            dist.all_to_all_single(recv, send, group=group)
+            from .dist_utils import all_to_all_single
+            all_to_all_single(recv, send, group=group)
 
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, attn: Callable) -> torch.Tensor:
         import torch.distributed as dist
@@ -200,7 +201,8 @@ class UlyssesAttention:
             if self._ag is not None:
                 self._ag(kv_, kv_part, ag_group)
             else:
-                dist.all_gather_into_tensor(kv_, kv_part, group=ag_group)
+                from .dist_utils import all_gather_into_tensor
+                all_gather_into_tensor(kv_, kv_part, group=ag_group)
             chunks = kv_.chunk(sp)
             kv_ordered = torch.cat([chunks[i] for i in self.order])
             k_, v_ = kv_ordered.split([kw, kw], dim=-1)

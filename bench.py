@@ -52,6 +52,10 @@ def parse_args():
     ap.add_argument("--no-shift-parallel", action="store_true",
                     help="N > 1: keep every step on the Ulysses all-to-all path (default: shift parallelism on, threshold "
                          "512 tokens, the reference's --enable-shift-parallel / --shift-parallel-threshold)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, the measured configuration) or gloo: a multi-process REHEARSAL of the N > 1 control "
+                         "flow with the ranks sharing the visible GPU(s) and collectives staged through the host "
+                         "(numbers are not a multi-GPU measurement)")
     ap.add_argument("--rehearse-sp", type=int, default=0,
                     help="single-GPU rehearsal of the SP=N code path: real pack/unpack/attention shapes of rank 0, "
                          "the all-to-all replaced by a local copy (numbers are NOT a multi-GPU measurement)")
@@ -126,13 +130,18 @@ def main():
     if world != args.gpus and world > 1:
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the hot path)"
+    if args.dist_backend == "gloo":
+        local_rank %= torch.cuda.device_count()      # rehearsal: ranks may share a device
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     from arcticinference_amd import _native as N
     from arcticinference_amd.engine import HotPathEngine, ModelShape, SpecConfig
@@ -233,8 +242,9 @@ def main():
     N.lib().aic_profile_read(ctypes.byref(tot_us), ctypes.byref(launches))
     N.lib().aic_profile_enable(0)
 
+    red_dev = dev if args.dist_backend == "nccl" else "cpu"
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     import copy
@@ -256,7 +266,7 @@ def main():
         barrier()
         a2a = time.perf_counter() - t1
         if dist is not None:
-            t = torch.tensor([a2a], dtype=torch.float64, device=dev)
+            t = torch.tensor([a2a], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             a2a = float(t.item())
         a2a_ms = a2a / k2 * 1e3
@@ -295,7 +305,8 @@ def main():
                              "attention, acceptance, suffix + LSTM proposal, KV write); target dense layers synthetic"
                              % (shape.num_layers, B, PL, GL, "bf16" if args.kv_dtype == "auto" else "fp8 e4m3")),
                 "global_batch": B, "prompt_len": PL, "gen_len": GL,
-                "parallelism": (("sp%d" % world + ("" if args.no_shift_parallel else "+shift(threshold 512 tokens)")) if world > 1
+                "parallelism": (("sp%d" % world + ("" if args.no_shift_parallel else "+shift(threshold 512 tokens)") +
+                                 ("" if args.dist_backend == "nccl" else " REHEARSAL over gloo, ranks share GPUs")) if world > 1
                                 else ("tp1" if args.rehearse_sp <= 1 else "REHEARSAL sp%d on one GPU" % args.rehearse_sp)),
             },
             "tokens_per_s_per_gpu": value / world,
