@@ -90,7 +90,8 @@ _SIGNATURES = {
                                                  c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
     "aic_rejection_workspace_bytes": (c_size_t, [c_int, c_int]),
     "aic_rejection_greedy": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                     c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                     c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p]),
     "aic_rejection_random": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p]),

@@ -92,14 +92,17 @@ logits_row_kernel(const T* __restrict__ logits, int64_t row_stride, int vocab, i
                   const int32_t* __restrict__ draft_ids, const int32_t* __restrict__ cu, int batch,
                   const float* __restrict__ temperature, const float* __restrict__ exp_noise,
                   float* __restrict__ part_val, int32_t* __restrict__ part_idx, float* __restrict__ stat_max,
-                  float* __restrict__ stat_sum, float* __restrict__ p_draft, const int64_t* __restrict__ row_index) {
+                  float* __restrict__ stat_sum, float* __restrict__ p_draft, const int64_t* __restrict__ row_index,
+                  const int64_t* __restrict__ bonus_row_index, int n_draft_rows) {
   constexpr int V = Elem<T>::kVec;
   const int row = blockIdx.x;
   const int seg = blockIdx.y;
   const int begin = seg * seg_len;
   const int end = min(begin + seg_len, vocab);
-  // row r of the call lives at logits[row_index[r]] when the caller passes the un-gathered [T, V] logits
-  const T* base = logits + (row_index ? row_index[row] : static_cast<int64_t>(row)) * row_stride;
+  // row r of the call lives at logits[row_index[r]] when the caller passes the un-gathered [T, V] logits; rows past
+  // the draft rows are the requests' bonus rows (greedy sampler folded into this launch)
+  const T* base = logits + (row >= n_draft_rows ? bonus_row_index[row - n_draft_rows]
+                                                : (row_index ? row_index[row] : static_cast<int64_t>(row))) * row_stride;
   __shared__ float s_v[4];
   __shared__ int s_i[4];
   __shared__ float s_m, s_z;
@@ -244,7 +247,7 @@ accept_kernel(const float* __restrict__ part_val, const int32_t* __restrict__ pa
               const int32_t* __restrict__ bonus, const float* __restrict__ temperature,
               const double* __restrict__ uniform, const float* __restrict__ p_draft, int max_spec_len,
               int32_t* __restrict__ out, int32_t* __restrict__ num_accepted, int32_t* __restrict__ last_token,
-              int32_t* __restrict__ hidden_index) {
+              int32_t* __restrict__ hidden_index, int bonus_part_row0) {
   const int req = blockIdx.x;
   const int lane = threadIdx.x;
   const int start = req == 0 ? 0 : cu[req - 1];
@@ -252,6 +255,23 @@ accept_kernel(const float* __restrict__ part_val, const int32_t* __restrict__ pa
   const int width = max_spec_len + 1;
   int32_t* orow = out + static_cast<int64_t>(req) * width;
 
+  // bonus token: the sampler's id, or (bonus_part_row0 >= 0) the arg-max partials of this request's bonus row
+  int bonus_tok;
+  if (bonus_part_row0 >= 0) {
+    const int brow = bonus_part_row0 + req;
+    Best b;
+    b.v = part_val[brow * n_splits];
+    b.i = part_idx[brow * n_splits];
+    for (int s = 1; s < n_splits; ++s) {
+      Best o;
+      o.v = part_val[brow * n_splits + s];
+      o.i = part_idx[brow * n_splits + s];
+      b = better(b, o);
+    }
+    bonus_tok = b.i;
+  } else {
+    bonus_tok = bonus[req];
+  }
   bool reject = false;
   int token = -1;
   if (lane < n) {
@@ -283,13 +303,13 @@ accept_kernel(const float* __restrict__ part_val, const int32_t* __restrict__ pa
   if (lane < width) {
     int32_t v = -1;
     if (lane < n && lane <= first_rej) v = token;
-    if (lane == n && first_rej == n) v = bonus[req];
+    if (lane == n && first_rej == n) v = bonus_tok;
     orow[lane] = v;
   }
   // what the proposer needs next (arctic_proposer.py:133-147)
   const int last_lane = written - 1;
   int last = __shfl(token, min(last_lane, 63));
-  if (last_lane == n) last = bonus[req];
+  if (last_lane == n) last = bonus_tok;
   if (lane == 0) {
     if (num_accepted) num_accepted[req] = written;
     if (last_token) last_token[req] = last;
@@ -310,29 +330,32 @@ template <typename T>
 static int run_rejection(const void* logits, int64_t row_stride, int vocab, const int32_t* draft,
                          const int32_t* cu, const int32_t* bonus, const float* temperature, const double* uniform,
                          const float* noise, int batch, int rows, int max_spec_len, int32_t* out, int32_t* nacc,
-                         int32_t* last, int32_t* hidx, const int64_t* row_index, void* workspace, hipStream_t stream, bool random) {
-  const int S = rows > 0 ? pick_splits(rows, vocab) : 1;  // a step without drafts still emits bonus tokens
+                         int32_t* last, int32_t* hidx, const int64_t* row_index, const int64_t* bonus_rows, void* workspace,
+                         hipStream_t stream, bool random) {
+  const int grid_rows = rows + (bonus_rows ? batch : 0);   // bonus rows are reduced in the same launch
+  const int S = grid_rows > 0 ? pick_splits(grid_rows, vocab) : 1;  // a step without drafts still emits bonus tokens
   int seg_len = (vocab + S - 1) / S;
   seg_len = (seg_len + kSegQuantum - 1) / kSegQuantum * kSegQuantum;
   const int n_splits = (vocab + seg_len - 1) / seg_len;
   float* part_val = static_cast<float*>(workspace);
-  int32_t* part_idx = reinterpret_cast<int32_t*>(part_val + static_cast<size_t>(rows) * kMaxSplits);
-  float* stat_max = reinterpret_cast<float*>(part_idx + static_cast<size_t>(rows) * kMaxSplits);
-  float* stat_sum = stat_max + static_cast<size_t>(rows) * kMaxSplits;
-  float* p_draft = stat_sum + static_cast<size_t>(rows) * kMaxSplits;
+  const size_t wr = static_cast<size_t>(grid_rows);
+  int32_t* part_idx = reinterpret_cast<int32_t*>(part_val + wr * kMaxSplits);
+  float* stat_max = reinterpret_cast<float*>(part_idx + wr * kMaxSplits);
+  float* stat_sum = stat_max + wr * kMaxSplits;
+  float* p_draft = stat_sum + wr * kMaxSplits;
   const T* lg = static_cast<const T*>(logits);
   const bool vec_ok = (reinterpret_cast<uintptr_t>(logits) % 16 == 0) && ((row_stride * sizeof(T)) % 16 == 0);
-  if (rows > 0) {
-    dim3 grid(rows, n_splits);
+  if (grid_rows > 0) {
+    dim3 grid(grid_rows, n_splits);
 #define AIC_ROW_LAUNCH(MODE)                                                                                      \
   if (vec_ok)                                                                                                     \
     hipLaunchKernelGGL((logits_row_kernel<T, MODE, true>), grid, dim3(256), 0, stream, lg, row_stride, vocab,     \
                        seg_len, n_splits, draft, cu, batch, temperature, noise, part_val, part_idx, stat_max,     \
-                       stat_sum, p_draft, row_index);                                                             \
+                       stat_sum, p_draft, row_index, bonus_rows, rows);                                           \
   else                                                                                                            \
     hipLaunchKernelGGL((logits_row_kernel<T, MODE, false>), grid, dim3(256), 0, stream, lg, row_stride, vocab,    \
                        seg_len, n_splits, draft, cu, batch, temperature, noise, part_val, part_idx, stat_max,     \
-                       stat_sum, p_draft, row_index);
+                       stat_sum, p_draft, row_index, bonus_rows, rows);
     if (!random) {
       AIC_ROW_LAUNCH(0)
     } else {
@@ -347,20 +370,22 @@ static int run_rejection(const void* logits, int64_t row_stride, int vocab, cons
   }
   if (random)
     hipLaunchKernelGGL((accept_kernel<true>), dim3(batch), dim3(64), 0, stream, part_val, part_idx, n_splits, draft,
-                       cu, bonus, temperature, uniform, p_draft, max_spec_len, out, nacc, last, hidx);
+                       cu, bonus, temperature, uniform, p_draft, max_spec_len, out, nacc, last, hidx, bonus_rows ? rows : -1);
   else
     hipLaunchKernelGGL((accept_kernel<false>), dim3(batch), dim3(64), 0, stream, part_val, part_idx, n_splits, draft,
-                       cu, bonus, temperature, uniform, p_draft, max_spec_len, out, nacc, last, hidx);
+                       cu, bonus, temperature, uniform, p_draft, max_spec_len, out, nacc, last, hidx, bonus_rows ? rows : -1);
   return launch_status("accept_kernel");
 }
 
 static int dispatch(const void* logits, int dtype, int64_t row_stride, int vocab, const int32_t* draft,
                     const int32_t* cu, const int32_t* bonus, const float* temperature, const double* uniform,
                     const float* noise, int batch, int rows, int max_spec_len, int32_t* out, int32_t* nacc,
-                    int32_t* last, int32_t* hidx, const int64_t* row_index, void* ws, void* stream, bool random) {
+                    int32_t* last, int32_t* hidx, const int64_t* row_index, const int64_t* bonus_rows, void* ws, void* stream,
+                    bool random) {
   if (batch == 0) return AIC_OK;
-  AIC_REQUIRE(cu && bonus && out && batch > 0 && rows >= 0 && vocab > 0, "bad arguments to rejection");
+  AIC_REQUIRE(cu && (bonus || bonus_rows) && out && batch > 0 && rows >= 0 && vocab > 0, "bad arguments to rejection");
   AIC_REQUIRE(rows == 0 || (logits && draft && ws), "null logits / draft ids / workspace");
+  AIC_REQUIRE(!bonus_rows || (!random && logits && ws), "bonus rows are folded into the greedy launch only");
   AIC_REQUIRE(max_spec_len >= 0 && max_spec_len + 1 <= 64, "max_spec_len must be <= 63 (one lane per position)");
   AIC_REQUIRE(!random || (temperature && uniform && noise), "random rejection needs temperature, uniform and noise");
   AIC_NEED_DEVICE();
@@ -368,13 +393,13 @@ static int dispatch(const void* logits, int dtype, int64_t row_stride, int vocab
   switch (dtype) {
     case AIC_DT_F32:
       return run_rejection<float>(logits, row_stride, vocab, draft, cu, bonus, temperature, uniform, noise, batch,
-                                  rows, max_spec_len, out, nacc, last, hidx, row_index, ws, s, random);
+                                  rows, max_spec_len, out, nacc, last, hidx, row_index, bonus_rows, ws, s, random);
     case AIC_DT_BF16:
       return run_rejection<bf16_t>(logits, row_stride, vocab, draft, cu, bonus, temperature, uniform, noise, batch,
-                                   rows, max_spec_len, out, nacc, last, hidx, row_index, ws, s, random);
+                                   rows, max_spec_len, out, nacc, last, hidx, row_index, bonus_rows, ws, s, random);
     case AIC_DT_F16:
       return run_rejection<f16_t>(logits, row_stride, vocab, draft, cu, bonus, temperature, uniform, noise, batch,
-                                  rows, max_spec_len, out, nacc, last, hidx, row_index, ws, s, random);
+                                  rows, max_spec_len, out, nacc, last, hidx, row_index, bonus_rows, ws, s, random);
     default:
       set_error("unsupported logits dtype %d", dtype);
       return AIC_ERR_UNSUPPORTED;
@@ -397,10 +422,11 @@ int aic_rejection_greedy(const void* target_logits, int logits_dtype, int64_t ro
                          const int32_t* draft_token_ids, const int32_t* cu_num_draft, const int32_t* bonus_token_ids,
                          int batch, int num_draft_total, int max_spec_len, int32_t* out_token_ids,
                          int32_t* num_accepted, int32_t* last_token, int32_t* hidden_index,
-                         const int64_t* target_row_index, void* workspace, void* stream) {
+                         const int64_t* target_row_index, const int64_t* bonus_row_index, void* workspace,
+                         void* stream) {
   return dispatch(target_logits, logits_dtype, row_stride, vocab, draft_token_ids, cu_num_draft, bonus_token_ids,
                   nullptr, nullptr, nullptr, batch, num_draft_total, max_spec_len, out_token_ids, num_accepted,
-                  last_token, hidden_index, target_row_index, workspace, stream, false);
+                  last_token, hidden_index, target_row_index, bonus_row_index, workspace, stream, false);
 }
 
 int aic_rejection_random(const void* target_logits, int logits_dtype, int64_t row_stride, int vocab,
@@ -411,7 +437,7 @@ int aic_rejection_random(const void* target_logits, int logits_dtype, int64_t ro
                          void* stream) {
   return dispatch(target_logits, logits_dtype, row_stride, vocab, draft_token_ids, cu_num_draft, bonus_token_ids,
                   temperature, uniform, exp_noise, batch, num_draft_total, max_spec_len, out_token_ids, num_accepted,
-                  last_token, hidden_index, target_row_index, workspace, stream, true);
+                  last_token, hidden_index, target_row_index, nullptr, workspace, stream, true);
 }
 
 }  // extern "C"

@@ -305,13 +305,10 @@ class HotPathEngine:
         col = d_plant.unsqueeze(1)
         saved = torch.gather(lg, 1, col)
         lg.scatter_(1, col, self._plant_col[:T])   # gather/scatter on device tensors only: nothing here may sync the stream
-        # vLLM's sampler on the bonus rows (gathered into a persistent buffer: no per-step allocation); the target rows
-        # are read in place by the acceptance kernel through their row indices (target_logits_indices)
-        if not hasattr(self, "_bonus_buf"):
-            self._bonus_buf = torch.empty(self.max_num_seqs, s.vocab_size, dtype=self.logits.dtype, device=dev)
-        bonus = torch.argmax(torch.index_select(lg, 0, d_brows, out=self._bonus_buf[:B]), dim=-1).to(torch.int32)
+        # greedy sampler on the bonus rows and the target rows of the acceptance: both read in place from the [T, V] logits
+        # through their row indices (bonus_logits_indices / target_logits_indices) inside one launch
         max_spec = int(max(n_draft.max(), 1))
-        rej = ops.rejection_sample(lg, d_draft, d_cu, bonus, max_spec, target_row_index=d_trows)
+        rej = ops.rejection_sample(lg, d_draft, d_cu, None, max_spec, target_row_index=d_trows, bonus_row_index=d_brows)
         lg.scatter_(1, col, saved)
 
         # (d) accepted tokens start their way to the host (pinned buffer, event) BEFORE the LSTM draft is

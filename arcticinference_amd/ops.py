@@ -114,34 +114,43 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 def rejection_sample(target_logits: torch.Tensor, draft_token_ids: torch.Tensor, cu_num_draft_tokens: torch.Tensor,
                      bonus_token_ids: torch.Tensor, max_spec_len: int, temperature: Optional[torch.Tensor] = None,
                      uniform_probs: Optional[torch.Tensor] = None, exp_noise: Optional[torch.Tensor] = None,
-                     target_row_index: Optional[torch.Tensor] = None) -> RejectionResult:
+                     target_row_index: Optional[torch.Tensor] = None,
+                     bonus_row_index: Optional[torch.Tensor] = None) -> RejectionResult:
     """out[B, max_spec_len+1] int32 (-1 padded) as vLLM's RejectionSampler returns it for
     draft_probs=None (call site model_runner.py:405-411), plus the proposer inputs of the next step.
     `target_row_index` (int64 [num_draft_total]): pass the model's full [T, V] logits as `target_logits` and the
-    rows to read (SpecDecodeMetadata.target_logits_indices) instead of a gathered copy."""
-    _need_cuda(target_logits, draft_token_ids, cu_num_draft_tokens, bonus_token_ids, target_row_index)
+    rows to read (SpecDecodeMetadata.target_logits_indices) instead of a gathered copy.  `bonus_row_index` (int64 [B],
+    greedy only): the bonus tokens are the arg-max of those rows of `target_logits`, computed in the same launch
+    (`bonus_token_ids` may then be None)."""
+    _need_cuda(target_logits, draft_token_ids, cu_num_draft_tokens, bonus_token_ids, target_row_index, bonus_row_index)
+    if bonus_row_index is not None and (temperature is not None or bonus_row_index.dtype != torch.int64 or
+                                        bonus_row_index.numel() != cu_num_draft_tokens.numel()):
+        raise ValueError("bonus_row_index: int64, one row per request, greedy acceptance only")
+    if bonus_token_ids is None and bonus_row_index is None:
+        raise ValueError("bonus_token_ids or bonus_row_index is required")
     if target_row_index is not None and (target_row_index.dtype != torch.int64 or
                                          target_row_index.numel() != draft_token_ids.numel()):
         raise ValueError("target_row_index must be int64 with one entry per draft token")
     B = cu_num_draft_tokens.numel()
     rows = draft_token_ids.numel()
-    V = target_logits.size(-1) if rows else 1
+    V = target_logits.size(-1) if (rows or bonus_row_index is not None) else 1
     dev = cu_num_draft_tokens.device
     out = torch.empty((B, max_spec_len + 1), dtype=torch.int32, device=dev)
     nacc = torch.empty(B, dtype=torch.int32, device=dev)
     last = torch.empty(B, dtype=torch.int32, device=dev)
     hidx = torch.empty(B, dtype=torch.int32, device=dev)
-    ws = _workspace(N.lib().aic_rejection_workspace_bytes(rows, V), dev)
+    ws = _workspace(N.lib().aic_rejection_workspace_bytes(rows + (B if bonus_row_index is not None else 0), V), dev)
     draft = draft_token_ids.to(torch.int32)
     cu = cu_num_draft_tokens.to(torch.int32)
-    bonus = bonus_token_ids.reshape(-1).to(torch.int32)
-    dt = N.torch_dtype_code(target_logits.dtype) if rows else N.DT_F32
-    stride = target_logits.stride(0) if rows else 0
+    bonus = None if bonus_token_ids is None else bonus_token_ids.reshape(-1).to(torch.int32)
+    has_logits = rows > 0 or bonus_row_index is not None
+    dt = N.torch_dtype_code(target_logits.dtype) if has_logits else N.DT_F32
+    stride = target_logits.stride(0) if has_logits else 0
     if temperature is None:
-        N.check(N.lib().aic_rejection_greedy(_ptr(target_logits) if rows else None, dt, stride, V, draft.data_ptr(),
-                                             cu.data_ptr(), bonus.data_ptr(), B, rows, max_spec_len, out.data_ptr(),
+        N.check(N.lib().aic_rejection_greedy(_ptr(target_logits) if has_logits else None, dt, stride, V, draft.data_ptr(),
+                                             cu.data_ptr(), _ptr(bonus), B, rows, max_spec_len, out.data_ptr(),
                                              nacc.data_ptr(), last.data_ptr(), hidx.data_ptr(), _ptr(target_row_index),
-                                             ws.data_ptr(), N.current_stream_ptr()))
+                                             _ptr(bonus_row_index), ws.data_ptr(), N.current_stream_ptr()))
     else:
         N.check(N.lib().aic_rejection_random(_ptr(target_logits) if rows else None, dt, stride, V, draft.data_ptr(),
                                              cu.data_ptr(), bonus.data_ptr(), temperature.float().data_ptr(),

@@ -173,6 +173,10 @@ int aic_reshape_and_cache_flash_bulk(const void* keys, const void* values, void*
  *     target_row_index (int64 [num_draft_total], may be NULL): row r of the call is
  *     target_logits[target_row_index[r]] — the caller passes the model's [T, vocab] logits and
  *     SpecDecodeMetadata.target_logits_indices (model_runner.py:404) instead of gathering the rows.
+ *     bonus_row_index (int64 [B], greedy entry point only, may be NULL): the bonus token of request i is the
+ *     arg-max of target_logits[bonus_row_index[i]] (the greedy sampler on bonus_logits_indices, model_runner.py:394,
+ *     folded into the same launch); bonus_token_ids may then be NULL and the workspace is sized for
+ *     num_draft_total + B rows.
  *     workspace: >= aic_rejection_workspace_bytes(num_draft_total, vocab) bytes of HBM.
  * ---------------------------------------------------------------------------------------- */
 size_t aic_rejection_workspace_bytes(int num_draft_total, int vocab);
@@ -180,7 +184,8 @@ int aic_rejection_greedy(const void* target_logits, int logits_dtype, int64_t ro
                          const int32_t* draft_token_ids, const int32_t* cu_num_draft,
                          const int32_t* bonus_token_ids, int batch, int num_draft_total, int max_spec_len,
                          int32_t* out_token_ids, int32_t* num_accepted, int32_t* last_token,
-                         int32_t* hidden_index, const int64_t* target_row_index, void* workspace, void* stream);
+                         int32_t* hidden_index, const int64_t* target_row_index, const int64_t* bonus_row_index,
+                         void* workspace, void* stream);
 /* Random rows (temperature > 0), draft_probs == None: accept draft iff softmax(logits/T)[draft] >= u,
  * else emit the recovered token argmax_v(p_v / q_v) with p[draft] := 0, q ~ Exp(1).
  * uniform: f64 [num_draft_total]; exp_noise: f32 [B][vocab]; temperature f32 [B]

@@ -143,6 +143,14 @@ def test_rejection_greedy(B, V, max_n, dtype):
                                        torch.tensor(bonus, dtype=torch.int32, device=DEV), max_n,
                                        target_row_index=pos.to(torch.int64).to(DEV))
         assert np.array_equal(res2.output_token_ids.cpu().numpy(), want)
+        # ... and with the bonus tokens taken as the arg-max of B more rows of that tensor, in the same launch
+        rest = [i for i in range(rows + B) if i not in set(pos.tolist())]
+        brow = torch.tensor(rest[:B], dtype=torch.int64)
+        bonus2 = torch.argmax(full[brow].float(), dim=-1).numpy()
+        want2 = O.rejection_greedy(logits, draft, n, bonus2, max_n)
+        res3 = _ops().rejection_sample(full.to(DEV), torch.tensor(draft, dtype=torch.int32, device=DEV), cu, None, max_n,
+                                       target_row_index=pos.to(torch.int64).to(DEV), bonus_row_index=brow.to(DEV))
+        assert np.array_equal(res3.output_token_ids.cpu().numpy(), want2)
 
 
 def test_rejection_random_mixed():

@@ -27,10 +27,19 @@ def timeit(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) / iters * 1e3  # us
 
 
-def attn(B=64, ctx=4096, qlen=4, Hq=32, Hkv=8, D=128, bs=16, layers=4, split=False):
+def attn(B=64, ctx=4096, qlen=4, Hq=32, Hkv=8, D=128, bs=16, layers=4, split=False, kv8=False):
     nblk = (ctx + bs - 1) // bs
     nb = B * nblk
     kvs = [torch.randn(2, nb, bs, Hkv, D, device=dev, dtype=torch.bfloat16) for _ in range(layers)]
+    kw = {}
+    if kv8:   # e4m3 cache: random codes without the NaN patterns
+        kvs = []
+        for _ in range(layers):
+            raw = torch.randint(0, 256, (2, nb, bs, Hkv, D), dtype=torch.uint8, device=dev)
+            raw[(raw & 0x7f) == 0x7f] = 0x30
+            kvs.append(raw.view(torch.float8_e4m3fn))
+        sc = torch.full((1,), 0.02, dtype=torch.float32, device=dev)
+        kw = dict(k_scale=sc, v_scale=sc)
     bt = torch.randperm(nb, device=dev).to(torch.int32).view(B, nblk)
     T = B * qlen
     q = torch.randn(T, Hq, D, device=dev, dtype=torch.bfloat16)
@@ -46,10 +55,10 @@ def attn(B=64, ctx=4096, qlen=4, Hq=32, Hkv=8, D=128, bs=16, layers=4, split=Fal
     def f():
         kv = kvs[i[0] % layers]
         i[0] += 1
-        ops.verify_attention(q, kv[0], kv[1], bt, seq, qsl, qlen, ctx, D ** -0.5, out=out, req_split=rs)
+        ops.verify_attention(q, kv[0], kv[1], bt, seq, qsl, qlen, ctx, D ** -0.5, out=out, req_split=rs, **kw)
     us = timeit(f)
-    gb = B * ctx * 2 * Hkv * D * 2 / 1e9
-    print(f"attn B={B} ctx={ctx} qlen={qlen} Hq={Hq} Hkv={Hkv} D={D}: {us:8.1f} us  {gb / us * 1e6 / 1e3:6.2f} TB/s (incl. combine)")
+    gb = B * ctx * 2 * Hkv * D * (1 if kv8 else 2) / 1e9
+    print(f"attn{' fp8kv' if kv8 else ''} B={B} ctx={ctx} qlen={qlen} Hq={Hq} Hkv={Hkv} D={D}: {us:8.1f} us  {gb / us * 1e6 / 1e3:6.2f} TB/s (incl. combine)")
 
 
 def lstm(B, fp8=True):
@@ -91,6 +100,9 @@ if __name__ == "__main__":
         attn(B=1, qlen=33, split=True)
         attn(B=64, Hq=64, Hkv=8, D=64)           # gpt-oss-120b heads (secondary head size: shared-tile body for all)
         attn(B=64, Hq=8, Hkv=1, D=64)            # its SP = 8 slice
+    if "fp8" in what or "attn" in what:
+        attn(split=True, kv8=True)
+        attn(B=16, qlen=33, split=True, kv8=True)
     if "long" in what:
         attn(B=16, qlen=33, split=True)
         attn(B=16, qlen=17, split=True)
