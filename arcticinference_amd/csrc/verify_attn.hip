@@ -982,6 +982,7 @@ verify_attn_pair_kernel(AttnParams PS, AttnParams PL, int n_long_wg, int n_long_
     verify_attn_long4_body<KV8, 128>(PL, lds, x, y, z);
   } else {
     const int sb = b - n_long_pad;
+    __builtin_amdgcn_s_setprio(3);   // the memory-bound short body sets the launch's end: its waves issue first
     verify_attn_body<MTQ, WH, KV8, 4>(PS, lds, sb % short_x, sb / short_x);
   }
 }
