@@ -806,8 +806,9 @@ int aic_sc_update_responses(aic_suffix_cache* c, int n_req, const int64_t* reqs,
     sid[r] = it->second;
   }
   // same order as one update_response per request.  (Extending the prompt trees on a helper thread while this
-  // thread extends the global tree was measured: slower, 0.28 -> 0.39 ms for 64 requests — thread start-up and
-  // allocator contention cost more than the ~150 appends it takes off this thread.)
+  // thread extends the global tree was measured twice — a thread per call and a parked worker woken per call — and was
+  // slower both times, 0.25 -> 0.35 ms for 64 requests, and slowed the speculation that follows: the second core's
+  // cache traffic costs more than the ~150 appends it takes off this thread.)
   for (int r = 0; r < n_req; ++r) {
     for (int64_t i = at[r]; i < at[r + 1]; ++i) c->global->host.append(sid[r], tokens[i]);
     auto pt = c->prompts.find(reqs[r]);
