@@ -293,6 +293,19 @@ class UlyssesContext:
 
         for layer in range(s.num_layers):
             self.attn.forward(q, k, v, lambda a, b, c, L=layer: attn(a, b, c, L))
+        # C6: the model's output rows of this rank's token slice, all-gathered over SP so that sampling and the draft
+        # model see every token (ulysses_forward, model_runner.py:202-209)
+        self.gather_hidden(eng.hidden[lo:lo + n], Tp)
+
+    def gather_hidden(self, local_rows: torch.Tensor, num_tokens: int) -> torch.Tensor:
+        """[N/SP, hidden] -> [N, hidden] over the SP group (one all-gather per step)."""
+        out = torch.empty((num_tokens, local_rows.shape[1]), dtype=local_rows.dtype, device=local_rows.device)
+        if self.group is None:          # single-process rehearsal: the collective is a local copy
+            out.copy_(local_rows.repeat(self.sp_size, 1))
+        else:
+            from .dist_utils import all_gather_into_tensor
+            all_gather_into_tensor(out, local_rows.contiguous(), group=self.group)
+        return out
 
 
 # --------------------------------------------------------------------------------------------------
