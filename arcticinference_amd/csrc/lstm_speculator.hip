@@ -216,7 +216,7 @@ __device__ __forceinline__ uint4 ld_stream16(const uint4* p) {
 }
 
 template <bool FP8, int MT, int EPI>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 skinny_gemm_kernel(const uint4* __restrict__ W, const uint4* __restrict__ X, int n_rowtiles, int steps_total,
                    int steps_per_split, float* __restrict__ part, int n_cols_out, const float* __restrict__ x_scale,
                    float w_scale, int n_valid_rows, int row_offset, float* __restrict__ best_val,
