@@ -80,3 +80,41 @@ def test_engine_steps_match_oracle_policy(method, with_lstm, head_size):
     assert st.emitted == sum(len(r.tokens) - 97 for r in eng.requests)
     assert st.accepted <= st.drafted and st.num_drafts > 0
     assert eng.suffix_cache._global_tree().selfcheck() == 0
+
+
+@pytest.mark.parametrize("method,with_lstm", [("suffix", False), ("arctic", True)])
+def test_engine_runs_to_the_model_length_limit(method, with_lstm):
+    """The reference's tests/unit_tests/test_arctic_spec_max_len.py asks that generation up to max_model_len (and 1, 2, 3
+    tokens short of it) works with both speculative methods.  Here: requests run into the limit, drafts are clamped so
+    that no request ever holds more than max_model_len tokens, finished requests leave the batch (it shrinks), and every
+    emitted token is the target's."""
+    from arcticinference_amd.workload import TokenSource
+    eng, spec = _build(method, with_lstm)
+    limit = eng.max_model_len                      # 400
+    src = TokenSource(vocab_size=2000, seed=8, n_motifs=3, motif_min=8, motif_max=16, p_motif=0.9)
+    plens = [limit - 3, limit - 40, limit - 12, limit - 90]
+    streams = {r: src.stream(limit + 40, r) for r in range(4)}
+    eng.add_requests(list(range(4)), list(range(4)), [streams[r][:plens[r]] for r in range(4)],
+                     [int(streams[r][plens[r]]) for r in range(4)])
+
+    def truth(req, n):
+        s = streams[req.req_id]
+        return s[len(req.tokens):len(req.tokens) + n]
+
+    finished = 0
+    for step in range(400):
+        for slot, r in enumerate(eng.requests):      # the scheduler retires a request at the length limit
+            if r is not None and len(r.tokens) >= limit:
+                eng.requests[slot] = None
+                finished += 1
+        live = [r for r in eng.requests if r is not None]
+        if not live:
+            break
+        before = {r.req_id: len(r.tokens) for r in live}
+        emitted = eng.step(truth)
+        for r, toks in zip(live, emitted):
+            assert len(r.tokens) <= limit, (step, r.req_id, len(r.tokens))
+            s = streams[r.req_id]
+            assert toks == [int(x) for x in s[before[r.req_id]:before[r.req_id] + len(toks)]]
+            assert len(r.tokens) + r.num_drafts <= limit, "a draft may not reach past the last position"
+    assert finished == 4
