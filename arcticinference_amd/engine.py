@@ -462,10 +462,11 @@ class HotPathEngine:
         if self.ulysses is None:
             q = self.q_buf[:T].view(T, s.num_q_heads, s.head_size)
             out = self.attn_out[:T].view(T, s.num_q_heads, s.head_size)
-            for layer in range(s.num_layers):
-                kv = self.kv[layer]
-                ops.verify_attention(q, kv[0], kv[1], bt, d_seq, d_qsl, max_q, max_ctx, self.sm_scale, out=out,
-                                     req_split=self._req_split, k_scale=self.kv_scale, v_scale=self.kv_scale,
-                                     stream=self._stream)
+            # one plan per step (the layers share the batch geometry), one foreign call per layer
+            plan = ops.VerifyAttentionPlan(q, out, self.kv[0][0], bt, d_seq, d_qsl, max_q, max_ctx, self.sm_scale,
+                                           req_split=self._req_split, k_scale=self.kv_scale, v_scale=self.kv_scale,
+                                           stream=self._stream)
+            for kv in self.kv:
+                plan.run(kv[0], kv[1])
         else:
             self.ulysses.attention_layers(self, T, bt, d_seq, d_qsl, max_q, max_ctx)

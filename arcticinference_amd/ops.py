@@ -197,6 +197,40 @@ def verify_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     return out
 
 
+class VerifyAttentionPlan:
+    """verify_attention for a caller that issues one call per layer with only the cache pointers changing (every layer
+    of a step shares the batch geometry): argument checks, workspace sizing and the ctypes argument list are built once
+    per step, `run(k_cache, v_cache)` is one foreign call.  Same semantics as verify_attention()."""
+
+    def __init__(self, q: torch.Tensor, out: torch.Tensor, kv_like: torch.Tensor, block_table: torch.Tensor,
+                 seq_lens: torch.Tensor, query_start_loc: torch.Tensor, max_q_len: int, max_seq_len: int, sm_scale: float,
+                 req_split=None, k_scale: Optional[torch.Tensor] = None, v_scale: Optional[torch.Tensor] = None,
+                 num_splits_max: int = 64, stream: Optional[int] = None):
+        _need_cuda(q, out, kv_like, block_table, seq_lens, query_start_loc)
+        T, Hq, D = q.shape
+        nb, bs, Hkv, D2 = kv_like.shape
+        assert D == D2 and q.stride(2) == 1 and q.stride(1) == D and out.shape == q.shape
+        ws = _workspace(N.lib().aic_verify_attention_workspace_bytes(T, Hq, D, num_splits_max), q.device)
+        short, n_short, long_, n_long = req_split if req_split is not None else (None, 0, None, 0)
+        self._keep = (q, out, block_table, seq_lens, query_start_loc, ws, short, long_, k_scale, v_scale)
+        self._fn = N.lib().aic_verify_attention_ex
+        self._args = [q.data_ptr(), q.stride(0), 0, 0, kv_like.stride(0), N.torch_dtype_code(kv_like.dtype), _ptr(k_scale),
+                      _ptr(v_scale), block_table.data_ptr(), block_table.size(1), seq_lens.data_ptr(),
+                      query_start_loc.data_ptr(), seq_lens.numel(), T, int(max_q_len), Hq, Hkv, D, bs, float(sm_scale),
+                      out.data_ptr(), out.stride(0), ws.data_ptr(), ws.numel(), int(max_seq_len),
+                      _ptr(short) if n_short else None, n_short, _ptr(long_) if n_long else None, n_long,
+                      N.current_stream_ptr() if stream is None else stream]
+        self._kv_shape, self._kv_dtype, self._kv_stride = tuple(kv_like.shape), kv_like.dtype, kv_like.stride(0)
+
+    def run(self, k_cache: torch.Tensor, v_cache: torch.Tensor) -> None:
+        if k_cache.shape != self._kv_shape or k_cache.dtype is not self._kv_dtype or k_cache.stride(0) != self._kv_stride:
+            raise ValueError("the plan was made for caches of another shape / dtype")
+        a = self._args
+        a[2] = k_cache.data_ptr()
+        a[3] = v_cache.data_ptr()
+        N.check(self._fn(*a))
+
+
 def split_order(q_lens_host: Sequence[int], group_size: int):
     """Host half of split_requests: (request ids with the short ones first, as int32; number of short requests), or
     None when every request is short (q_len * Hq/Hkv <= 16 rows, or <= 32 rows when Hq/Hkv > 4)."""

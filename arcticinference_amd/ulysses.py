@@ -272,10 +272,11 @@ class UlyssesContext:
             h0, h1 = sp_tp_head_slice(s.num_q_heads, sp, 1, self.sp_rank, 0)
             q_loc = eng.q_buf[:T].view(T, s.num_q_heads, D)[:, h0:h1]          # strided view, row stride Hq * D
             out = eng.attn_out[:T].view(T, hq, D)
-            for layer in range(s.num_layers):
-                kv = eng.kv[layer]
-                ops.verify_attention(q_loc, kv[0], kv[1], bt, d_seq, d_qsl, max_q, max_ctx, eng.sm_scale, out=out,
-                                     req_split=eng._req_split, k_scale=eng.kv_scale, v_scale=eng.kv_scale, stream=eng._stream)
+            plan = ops.VerifyAttentionPlan(q_loc, out, eng.kv[0][0], bt, d_seq, d_qsl, max_q, max_ctx, eng.sm_scale,
+                                           req_split=eng._req_split, k_scale=eng.kv_scale, v_scale=eng.kv_scale,
+                                           stream=eng._stream)
+            for kv in eng.kv:
+                plan.run(kv[0], kv[1])
             return
         self.steps_sp += 1
         # this rank's token slice x all heads, as the dense layers of the target would hand it over

@@ -289,6 +289,26 @@ def test_verify_attention_head_size_64(cfg):
         assert torch.allclose(got.float().cpu(), want, atol=1e-3, rtol=2 ** -8), (extra, (got.float().cpu() - want).abs().max())
 
 
+def test_verify_attention_plan_equals_direct_call():
+    """VerifyAttentionPlan (arguments built once, one foreign call per layer) gives the bits of verify_attention()."""
+    D, Hq, Hkv = 128, 32, 8
+    q_lens, ctxs = [4, 33, 2, 17, 4], [900, 1300, 64, 2100, 33]
+    q, kc, vc, bt, qsl = _attn_case(5, Hq, Hkv, D, q_lens, ctxs, 16, seed=3)
+    ops = _ops()
+    dq, dk, dv, dbt = q.to(DEV), kc.to(DEV), vc.to(DEV), bt.to(DEV)
+    seq = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
+    dqsl = torch.tensor(qsl, device=DEV)
+    rs = ops.split_requests(q_lens, Hq // Hkv, DEV)
+    want = ops.verify_attention(dq, dk, dv, dbt, seq, dqsl, max(q_lens), max(ctxs), D ** -0.5, req_split=rs)
+    out = torch.empty_like(dq)
+    plan = ops.VerifyAttentionPlan(dq, out, dk, dbt, seq, dqsl, max(q_lens), max(ctxs), D ** -0.5, req_split=rs)
+    k2, v2 = dk.clone(), dv.clone()          # another "layer": same shapes, other addresses
+    plan.run(k2, v2)
+    assert torch.equal(out, want)
+    with pytest.raises(ValueError):
+        plan.run(dk[:-1], dv[:-1])
+
+
 def test_verify_attention_unsupported_shapes():
     from arcticinference_amd._native import NativeError
     q, kc, vc, bt, qsl = _attn_case(1, 4, 1, 96, [2], [40], 16, seed=1)
