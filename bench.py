@@ -278,11 +278,16 @@ def main():
         avg_launch_us = tot_us.value / max(launches.value, 1)
         bytes_per_launch = attn_bytes[0] / max(args.steps * shape.num_layers, 1)   # every launch of a step moves the same bytes
         achieved = bytes_per_launch / (avg_launch_us * 1e-6) / 1e9 if launches.value else 0.0
+        # PMC-measured HBM bytes per launch (profiles/r01_pmc_attention.json, tools/pmc_summary.py): recorded for the
+        # default single-GPU workload only; any other shape reports null rather than a number that is not its own
         traffic = None
+        default_shape = (world == 1 and args.rehearse_sp <= 1 and args.kv_dtype == "auto" and B == 64 and PL == 4096
+                         and GL == 256 and shape.num_layers == 32 and not args.no_lstm)
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_attention.json")
-        if os.path.exists(pmc):
+        if default_shape and os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                with open(pmc) as f:
+                    traffic = json.load(f).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
