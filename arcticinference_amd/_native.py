@@ -75,6 +75,7 @@ _SIGNATURES = {
     "aic_sc_destroy": (None, [c_void_p]),
     "aic_sc_has_prompt": (c_int, [c_void_p, c_int64]),
     "aic_sc_cache_prompt": (c_int, [c_void_p, c_int64, c_void_p, c_int]),
+    "aic_sc_cache_prompt_async": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int]),
     "aic_sc_cache_prompts": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int]),
     "aic_sc_evict_prompt": (c_int, [c_void_p, c_int64]),
     "aic_sc_update_response": (c_int, [c_void_p, c_int64, c_void_p, c_int]),

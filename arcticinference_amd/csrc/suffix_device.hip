@@ -272,11 +272,21 @@ class Mirror;
 
 struct aic_suffix_tree {
   explicit aic_suffix_tree(int depth) : host(depth) {}
+  ~aic_suffix_tree() { join_build(); }
   aic::HostTree host;
   aic::TreeImage img;
   aic::DevPool* pool = nullptr;           // who owns img's buffers
   std::unique_ptr<aic::Mirror> own;       // standalone trees mirror themselves
   std::unique_ptr<aic::DevPool> own_pool;
+  // a prompt tree may still be under construction on a host thread (aic_sc_cache_prompt_async): whoever touches
+  // `host` or `img` first joins it
+  std::thread builder;
+  void join_build() {
+    if (builder.joinable()) builder.join();
+  }
+  // the device image is stale beyond what the dirty lists say (a mirror batch failed after this tree's deltas were
+  // collected): the next add_tree uploads the whole tree
+  bool force_full = false;
 };
 
 namespace aic {
@@ -299,6 +309,13 @@ class Mirror {
     jobs_.clear();
     descs_.clear();
     max_job_words_ = 0;
+    batch_trees_.clear();
+  }
+  // a step of the current batch failed: the device images of its trees may lack deltas whose dirty marks are gone
+  int fail_batch(int rc) {
+    for (aic_suffix_tree* t : batch_trees_) t->force_full = true;
+    batch_trees_.clear();
+    return rc;
   }
 
   // reserves `n` int32 words (16-byte aligned start) in the pinned blob, returns the word offset
@@ -358,17 +375,23 @@ class Mirror {
 
   // Queues everything tree `t` changed since its last mirror; returns its TreeDesc index.
   int add_tree(aic_suffix_tree* t, DevPool& pool, int* desc_index) {
+    t->join_build();
     HostTree& H = t->host;
     TreeImage& I = t->img;
     t->pool = &pool;
     bool moved = false;
     int rc;
     int64_t off, ioff;
+    // from here on the dirty information of `t` is consumed before the device has applied it: a failure anywhere in
+    // this batch (allocation, copy, launch) marks every tree of the batch for a full upload (fail_batch())
+    batch_trees_.push_back(t);
+    const bool full = t->force_full;
+    t->force_full = false;
 
     // nodes
     const size_t n_nodes = H.recs().size();
     if ((rc = grow(pool, &I.nodes, &I.nodes_cap, n_nodes, &moved)) != AIC_OK) return rc;
-    if (moved) {
+    if (moved || full) {
       if ((rc = reserve(n_nodes * 8, &off)) != AIC_OK) return rc;
       std::memcpy(at(off), H.recs().data(), n_nodes * sizeof(NodeRec));
       add_job(I.nodes, off, -1, 0, static_cast<int32_t>(n_nodes), 8);
@@ -389,7 +412,7 @@ class Mirror {
     // hash table
     const size_t n_slots = H.slots().size();
     if ((rc = grow(pool, &I.hash, &I.hash_cap, n_slots, &moved)) != AIC_OK) return rc;
-    if (moved || H.hash_rebuilt()) {
+    if (moved || full || H.hash_rebuilt()) {
       if ((rc = reserve(n_slots * 4, &off)) != AIC_OK) return rc;
       std::memcpy(at(off), H.slots().data(), n_slots * sizeof(HashSlot));
       add_job(I.hash, off, -1, 0, static_cast<int32_t>(n_slots), 4);
@@ -412,7 +435,7 @@ class Mirror {
     bool any_moved = false;
     for (auto& s : seqs) any_moved |= H.fit_region(s, static_cast<int32_t>(s.toks.size()));
     if ((rc = grow(pool, &I.tokens, &I.tokens_cap, static_cast<size_t>(H.pool_end()), &moved)) != AIC_OK) return rc;
-    if (moved)
+    if (moved || full)
       for (auto& s : seqs) s.synced = 0;
     for (auto& s : seqs) {
       const int32_t have = static_cast<int32_t>(s.toks.size());
@@ -426,7 +449,7 @@ class Mirror {
     }
     // seq_base table
     if ((rc = grow(pool, &I.seq_base, &I.seq_cap, std::max<size_t>(seqs.size(), 1), &moved)) != AIC_OK) return rc;
-    if (moved || any_moved || I.seq_synced != seqs.size()) {
+    if (moved || full || any_moved || I.seq_synced != seqs.size()) {
       if ((rc = reserve(std::max<size_t>(seqs.size(), 1), &off)) != AIC_OK) return rc;
       for (size_t k = 0; k < seqs.size(); ++k) at(off)[k] = seqs[k].base;
       add_job(I.seq_base, off, -1, 0, static_cast<int32_t>(seqs.size()), 1);
@@ -451,6 +474,15 @@ class Mirror {
   int run(const std::vector<QueryRec>& queries, const std::vector<int32_t>& pattern_pool, int n_starts, int cap,
           int32_t* out_tokens, float* out_probs, int32_t* out_n, float* out_score, int32_t* out_match,
           hipStream_t stream) {
+    const int rc = run_batch(queries, pattern_pool, n_starts, cap, out_tokens, out_probs, out_n, out_score, out_match, stream);
+    if (rc != AIC_OK) return fail_batch(rc);
+    batch_trees_.clear();   // the deltas are on the device (stream synchronised): the sync state stands
+    return AIC_OK;
+  }
+
+  int run_batch(const std::vector<QueryRec>& queries, const std::vector<int32_t>& pattern_pool, int n_starts, int cap,
+                int32_t* out_tokens, float* out_probs, int32_t* out_n, float* out_score, int32_t* out_match,
+                hipStream_t stream) {
     const int nq = static_cast<int>(queries.size());
     int rc;
     int64_t q_off, p_off, d_off, j_off;
@@ -557,6 +589,7 @@ class Mirror {
   std::vector<ApplyJob> jobs_;
   std::vector<TreeDesc> descs_;
   int64_t max_job_words_ = 0;
+  std::vector<aic_suffix_tree*> batch_trees_;
   int32_t* dblob_ = nullptr;
   size_t dblob_cap_ = 0;
   int32_t* dscr_ = nullptr;
@@ -584,7 +617,10 @@ struct aic_suffix_cache {
   explicit aic_suffix_cache(int depth) : max_depth(depth), global(new aic_suffix_tree(depth)) {}
   ~aic_suffix_cache() {
     // trees hand their buffers back to `pool` before the pool frees them
-    for (auto& kv : prompts) aic::release_image(kv.second.get());
+    for (auto& kv : prompts) {
+      kv.second->join_build();
+      aic::release_image(kv.second.get());
+    }
     aic::release_image(global.get());
   }
   int max_depth;
@@ -655,7 +691,7 @@ int aic_st_speculate(aic_suffix_tree* t, const int32_t* pattern, int n, int max_
   mir.begin();
   int di = -1;
   int rc = mir.add_tree(t, pool, &di);
-  if (rc != AIC_OK) return rc;
+  if (rc != AIC_OK) return mir.fail_batch(rc);
   QueryRec q;
   q.pattern_off = 0;
   q.pattern_len = n;
@@ -736,6 +772,32 @@ int aic_sc_cache_prompt(aic_suffix_cache* c, int64_t req, const int32_t* tokens,
   c->prompts.emplace(req, std::move(t));
   return AIC_OK;
 }
+int aic_sc_cache_prompt_async(aic_suffix_cache* c, int64_t req, const int32_t* tokens, int n, const int32_t* response,
+                              int n_response) {
+  AIC_REQUIRE(c && (tokens || n == 0) && n >= 0 && (response || n_response == 0) && n_response >= 0,
+              "bad arguments to aic_sc_cache_prompt_async");
+  if (c->prompts.count(req)) {
+    set_error("prompt already exists for request %lld", static_cast<long long>(req));
+    return AIC_ERR_EXISTS;
+  }
+  // the global tree is this thread's: the response tokens go in now, in call order (suffix_cache.py:141-149)
+  if (n_response > 0) {
+    auto it = c->seq_of.find(req);
+    if (it == c->seq_of.end()) it = c->seq_of.emplace(req, static_cast<int32_t>(c->seq_of.size())).first;
+    for (int i = 0; i < n_response; ++i) c->global->host.append(it->second, response[i]);
+  }
+  // the prompt tree is independent of everything else until somebody asks for it: build it on a host thread
+  std::unique_ptr<aic_suffix_tree> t(new aic_suffix_tree(c->max_depth));
+  std::vector<int32_t> all(static_cast<size_t>(n) + n_response);
+  if (n) std::memcpy(all.data(), tokens, static_cast<size_t>(n) * 4);
+  if (n_response) std::memcpy(all.data() + n, response, static_cast<size_t>(n_response) * 4);
+  aic_suffix_tree* raw = t.get();
+  t->builder = std::thread([raw, toks = std::move(all)]() {
+    for (int32_t tok : toks) raw->host.append(0, tok);
+  });
+  c->prompts.emplace(req, std::move(t));
+  return AIC_OK;
+}
 int aic_sc_cache_prompts(aic_suffix_cache* c, int n_req, const int64_t* reqs, const int32_t* tokens,
                          const int32_t* lens, int n_threads) {
   AIC_REQUIRE(c && reqs && lens && n_req >= 0, "bad arguments to aic_sc_cache_prompts");
@@ -774,6 +836,7 @@ int aic_sc_evict_prompt(aic_suffix_cache* c, int64_t req) {
     set_error("prompt does not exist for request %lld", static_cast<long long>(req));
     return AIC_ERR_NOT_FOUND;
   }
+  it->second->join_build();
   release_image(it->second.get());
   c->prompts.erase(it);
   return AIC_OK;
@@ -785,8 +848,10 @@ int aic_sc_update_response(aic_suffix_cache* c, int64_t req, const int32_t* toke
   const int32_t sid = it->second;
   for (int i = 0; i < n; ++i) c->global->host.append(sid, tokens[i]);
   auto pt = c->prompts.find(req);
-  if (pt != c->prompts.end())
+  if (pt != c->prompts.end()) {
+    pt->second->join_build();
     for (int i = 0; i < n; ++i) pt->second->host.append(0, tokens[i]);
+  }
   return AIC_OK;
 }
 
@@ -812,8 +877,10 @@ int aic_sc_update_responses(aic_suffix_cache* c, int n_req, const int64_t* reqs,
   for (int r = 0; r < n_req; ++r) {
     for (int64_t i = at[r]; i < at[r + 1]; ++i) c->global->host.append(sid[r], tokens[i]);
     auto pt = c->prompts.find(reqs[r]);
-    if (pt != c->prompts.end())
+    if (pt != c->prompts.end() && at[r + 1] > at[r]) {
+      pt->second->join_build();
       for (int64_t i = at[r]; i < at[r + 1]; ++i) pt->second->host.append(0, tokens[i]);
+    }
   }
   return AIC_OK;
 }
@@ -843,7 +910,7 @@ int aic_sc_speculate_batch(aic_suffix_cache* c, int n_query, const int64_t* reqs
   Mirror& mir = c->mirror;
   mir.begin();
   int rc, gdesc = -1;
-  if ((rc = mir.add_tree(c->global.get(), c->pool, &gdesc)) != AIC_OK) return rc;
+  if ((rc = mir.add_tree(c->global.get(), c->pool, &gdesc)) != AIC_OK) return mir.fail_batch(rc);
   std::unordered_map<int64_t, int> pdesc;
   std::vector<QueryRec> qs(n_query);
   std::vector<int32_t> pool_words;
@@ -871,7 +938,7 @@ int aic_sc_speculate_batch(aic_suffix_cache* c, int n_query, const int64_t* reqs
       auto it = pdesc.find(reqs[i]);
       if (it == pdesc.end()) {
         int di = -1;
-        if ((rc = mir.add_tree(c->prompts[reqs[i]].get(), c->pool, &di)) != AIC_OK) return rc;
+        if ((rc = mir.add_tree(c->prompts[reqs[i]].get(), c->pool, &di)) != AIC_OK) return mir.fail_batch(rc);
         it = pdesc.emplace(reqs[i], di).first;
       }
       q.prompt_tree = it->second;
@@ -888,7 +955,10 @@ int aic_sc_last_stats(const aic_suffix_cache* c, float* match_us, int64_t* mirro
   if (mirrored_bytes) *mirrored_bytes = c->mirror.mirrored_bytes();
   if (n_nodes_total) {
     int64_t n = static_cast<int64_t>(c->global->host.num_nodes());
-    for (const auto& kv : c->prompts) n += static_cast<int64_t>(kv.second->host.num_nodes());
+    for (const auto& kv : c->prompts) {
+      kv.second->join_build();
+      n += static_cast<int64_t>(kv.second->host.num_nodes());
+    }
     *n_nodes_total = n;
   }
   return AIC_OK;
@@ -897,7 +967,9 @@ aic_suffix_tree* aic_sc_global_tree(aic_suffix_cache* c) { return c ? c->global.
 aic_suffix_tree* aic_sc_prompt_tree(aic_suffix_cache* c, int64_t req) {
   if (!c) return nullptr;
   auto it = c->prompts.find(req);
-  return it == c->prompts.end() ? nullptr : it->second.get();
+  if (it == c->prompts.end()) return nullptr;
+  it->second->join_build();
+  return it->second.get();
 }
 
 }  // extern "C"

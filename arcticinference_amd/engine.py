@@ -40,6 +40,11 @@ class SpecConfig:
     suffix_max_spec_offset: float = 0.0
     suffix_min_token_prob: float = 0.1
     disable_by_batch_size: int = 64
+    # The reference's propose_arctic_draft_token_ids returns no draft for ANY request of a step in which some request
+    # was taken by suffix decoding (model_runner.py:616-618: an emptied sampled list + enable_suffix_decoding ends the
+    # whole batch's draft-model proposal).  False reproduces that; True is this build's extension: the draft model
+    # still serves the requests suffix decoding did not take.
+    draft_model_per_request: bool = False
 
 
 @dataclass
@@ -165,7 +170,7 @@ class HotPathEngine:
         self.requests: List[Optional[RequestState]] = [None] * max_num_seqs
         # vLLM's input_batch.token_ids_cpu: prompt + sampled tokens per slot (the suffix patterns are slices of it)
         self.token_ids_cpu = np.zeros((max_num_seqs, max_model_len + MAX_SPEC_LEN + 2), dtype=np.int32)
-        self.block_table = torch.zeros(max_num_seqs, self.blocks_per_seq, dtype=torch.int32, device=self.device)
+        self.block_table = torch.from_numpy(self._bt_host).to(self.device)   # int32 [max_num_seqs, blocks_per_seq]
         self.sm_scale = s.head_size ** -0.5
         self._plant_col = torch.full((self.max_tokens, 1), 30.0, dtype=torch.bfloat16, device=self.device)
         self.stats = StepStats()
@@ -173,20 +178,21 @@ class HotPathEngine:
         self.timeline: Dict[str, float] = {}   # seconds accumulated per phase (host clock)
 
     # -- request management ---------------------------------------------------------------------------
-    def add_request(self, slot: int, req_id, prompt: Sequence[int], first_token: int) -> None:
+    def add_request(self, slot: int, req_id, prompt: Sequence[int], first_token) -> None:
         """Admit a request whose prompt has been prefilled (its KV is taken as resident) and whose first
-        token has been sampled.  Mirrors the first pass through _update_suffix_cache (:657-673)."""
+        token has been sampled (`first_token`: that token, or the list of tokens generated so far for a request
+        that joins mid-generation).  Mirrors the first pass through _update_suffix_cache (:657-673); the prompt tree
+        is built on a host thread while the next step's attention runs (SuffixCache.cache_prompt_async)."""
         old = self.requests[slot]
         blocks = self._free_blocks[slot]
         r = RequestState(req_id, prompt, blocks)
         self.requests[slot] = r
-        self.block_table[slot].copy_(torch.from_numpy(blocks), non_blocking=False)
+        gen = [int(first_token)] if np.isscalar(first_token) else [int(t) for t in first_token]
         if self.suffix_cache is not None:
             if old is not None and self.suffix_cache.has_cached_prompt(old.req_id):
                 self.suffix_cache.evict_prompt(old.req_id)   # model_runner.py:675-678
-            self.suffix_cache.cache_prompt(req_id, r.tokens[:r.num_prompt])
-            self.suffix_cache.update_response(req_id, [int(first_token)])
-        r.tokens.append(int(first_token))
+            self.suffix_cache.cache_prompt_async(req_id, r.tokens[:r.num_prompt], gen)
+        r.tokens.extend(gen)
         self.token_ids_cpu[slot, :len(r.tokens)] = r.tokens
 
     def add_requests(self, slots, req_ids, prompts, first_tokens, n_threads: int = 8) -> None:
@@ -199,10 +205,10 @@ class HotPathEngine:
         for s, rid, p, ft in zip(slots, req_ids, prompts, first_tokens):
             r = RequestState(rid, p, self._free_blocks[s])
             self.requests[s] = r
-            self.block_table[s].copy_(torch.from_numpy(r.blocks))
+            gen = [int(ft)] if np.isscalar(ft) else [int(t) for t in ft]
             if self.suffix_cache is not None:
-                self.suffix_cache.update_response(rid, [int(ft)])
-            r.tokens.append(int(ft))
+                self.suffix_cache.update_response(rid, gen)
+            r.tokens.extend(gen)
             self.token_ids_cpu[s, :len(r.tokens)] = r.tokens
 
     # -- one engine step --------------------------------------------------------------------------------
@@ -322,7 +328,14 @@ class HotPathEngine:
         self._out_ev.record()
         lstm_out = None
         use_lstm = spec.method in ("arctic", "mlp_speculator") and self.drafter is not None and B <= spec.disable_by_batch_size
-        if use_lstm:
+        # Under the reference's rule (SpecConfig.draft_model_per_request = False) the draft model's output is dropped
+        # whenever suffix decoding takes any request of the step, which the host only learns after the suffix round trip.
+        # Steps follow each other closely in what they do, so: if the previous step used the draft model, enqueue it
+        # now (it runs while the host updates the trees) and drop it should suffix decoding win; if the previous step
+        # was taken by suffix decoding, wait for the suffix result and run the draft model only if nobody was taken.
+        early_lstm = use_lstm and (spec.draft_model_per_request or self.suffix_cache is None or
+                                   not getattr(self, "_suffix_won_last", False))
+        if early_lstm:
             lstm_out = self.drafter.generate_proposals(rej.last_token, self.hidden, spec.num_speculative_tokens,
                                                        hidden_index=rej.hidden_index)
         _mark('enqueue_accept_and_draft')
@@ -367,6 +380,18 @@ class HotPathEngine:
         # (f) merge (:555-566, :595-601).  The LSTM tokens start their copy to the host (the reference's `.cpu()`,
         # arctic_proposer.py:166) but nothing here waits for it: which requests take the LSTM draft, and how many
         # tokens, is known from the suffix result alone, and the next step fills the ids in on the device.
+        min_score = 0 if spec.method == "suffix" else spec.num_speculative_tokens
+        took = None
+        if suffix is not None:
+            took = (suffix[1] > 0) & (suffix[2] >= min_score)
+        suffix_won = bool(took is not None and took.any())
+        self._suffix_won_last = suffix_won
+        if use_lstm and not spec.draft_model_per_request:
+            if suffix_won:
+                lstm_out = None                       # model_runner.py:616-618: no draft-model proposal this step
+            elif lstm_out is None:
+                lstm_out = self.drafter.generate_proposals(rej.last_token, self.hidden, spec.num_speculative_tokens,
+                                                           hidden_index=rej.hidden_index)
         pend = None
         if lstm_out is not None:
             if not hasattr(self, "_lstm_pin"):
@@ -380,14 +405,18 @@ class HotPathEngine:
             ev.record()
             pend = _PendingDrafts(pin, ev, [])
         self._lstm_prev = lstm_out
-        min_score = 0 if spec.method == "suffix" else spec.num_speculative_tokens
+        # the draft model's length clamp is ONE value for the batch in the reference (the running minimum of
+        # propose_arctic_draft_token_ids, model_runner.py:629-641); the per-request extension clamps per request
+        k_batch = spec.num_speculative_tokens
+        if pend is not None and not spec.draft_model_per_request:
+            k_batch = max(min(k_batch, self.max_model_len - max(len(r.tokens) for r in reqs) - 1), 0)
         for i, r in enumerate(reqs):
             room = self.max_model_len - len(r.tokens) - 1
-            if suffix is not None and suffix[1][i] > 0 and suffix[2][i] >= min_score:
+            if took is not None and took[i]:
                 r.drafts = suffix[0][i, :suffix[1][i]].tolist()[:max(room, 0)]
                 self.stats.suffix_used += 1
             elif pend is not None and n_emit[i]:
-                k = max(min(spec.num_speculative_tokens, room), 0)
+                k = max(min(k_batch, room), 0)
                 r.drafts = [0] * k                          # placeholders until the copy lands
                 if k:
                     r._pending, r.draft_row = pend, i

@@ -159,6 +159,19 @@ class SuffixCache:
         N.check(N.lib().aic_sc_cache_prompt(self._h, self._key(req_id), a.ctypes.data, a.size))
         self._prompt_ids[req_id] = True
 
+    def cache_prompt_async(self, req_id: Hashable, prompt_token_ids: Sequence[int],
+                           response_token_ids: Sequence[int] = ()):
+        """cache_prompt(req_id, prompt) + update_response(req_id, response) with the prompt tree built on a host
+        thread (the caller knows the prompt before it needs the tree: while the request is being prefilled).  The
+        first call that touches the request's prompt tree waits for the build; results equal the synchronous calls."""
+        if req_id in self._prompt_ids:
+            raise ValueError(f"Prompt already exists for request '{req_id}'")
+        a = _i32(prompt_token_ids)
+        r = _i32(response_token_ids)
+        N.check(N.lib().aic_sc_cache_prompt_async(self._h, self._key(req_id), a.ctypes.data, a.size,
+                                                  r.ctypes.data if r.size else None, r.size))
+        self._prompt_ids[req_id] = True
+
     def cache_prompts(self, req_ids: Sequence[Hashable], prompts: Sequence[Sequence[int]], n_threads: int = 8):
         """Several prompts at once; the independent prompt trees are built on host threads."""
         for r in req_ids:

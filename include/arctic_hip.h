@@ -112,6 +112,14 @@ int aic_sc_cache_prompt(aic_suffix_cache* c, int64_t req, const int32_t* tokens 
 /* builds several prompt trees concurrently on host threads (independent trees) */
 int aic_sc_cache_prompts(aic_suffix_cache* c, int n_req, const int64_t* reqs, const int32_t* tokens /*host, concatenated*/,
                          const int32_t* lens, int n_threads);
+/* cache_prompt (suffix_cache.py:75-96) followed by update_response(req, response) (:118-149) for a request whose
+ * prompt tree is not needed yet (vLLM knows a request's prompt when its prefill is scheduled; the reference builds the
+ * tree on the engine thread at the first sampled token, model_runner.py:664-671, 3-4 ms per 4096-token prompt): the
+ * response tokens enter the global tree now, in call order, and the prompt tree (prompt + response) is built on a host
+ * thread.  Every later call that reads or extends that prompt tree joins the build first, so results are those of the
+ * synchronous pair of calls.  AIC_ERR_EXISTS as aic_sc_cache_prompt. */
+int aic_sc_cache_prompt_async(aic_suffix_cache* c, int64_t req, const int32_t* tokens /*host*/, int n,
+                              const int32_t* response /*host, may be NULL*/, int n_response);
 /* evict_prompt suffix_cache.py:98-111 (AIC_ERR_NOT_FOUND -> ValueError) */
 int aic_sc_evict_prompt(aic_suffix_cache* c, int64_t req);
 /* update_response suffix_cache.py:118-149; seq ids are dense in first-seen order (:113-116) */

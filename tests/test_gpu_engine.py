@@ -11,12 +11,13 @@ from oracle.suffix_oracle import OracleSuffixCache
 pytestmark = pytest.mark.gpu
 
 
-def _build(method, with_lstm, head_size=128):
+def _build(method, with_lstm, head_size=128, per_request=False):
     from arcticinference_amd.engine import HotPathEngine, ModelShape, SpecConfig
     from arcticinference_amd.speculator import ArcticLSTMSpeculator, LSTMSpeculatorConfig, random_lstm_weights
     shape = ModelShape(num_layers=2, num_q_heads=8, num_kv_heads=4, head_size=head_size, hidden_size=512, vocab_size=2000,
                        block_size=16)
-    spec = SpecConfig(method=method, num_speculative_tokens=3, enable_suffix_decoding=True)
+    spec = SpecConfig(method=method, num_speculative_tokens=3, enable_suffix_decoding=True,
+                      draft_model_per_request=per_request)
     drafter = None
     if with_lstm:
         cfg = LSTMSpeculatorConfig(vocab_size=2000, input_hidden_dim=512, inner_dim="512", emb_dim="512", proj_dim="512")
@@ -25,11 +26,14 @@ def _build(method, with_lstm, head_size=128):
     return HotPathEngine(shape, spec, 4, 400, drafter, device="cuda", seed=0), spec
 
 
-@pytest.mark.parametrize("method,with_lstm,head_size", [("suffix", False, 128), ("arctic", True, 128), ("arctic", True, 64)])
-def test_engine_steps_match_oracle_policy(method, with_lstm, head_size):
+@pytest.mark.parametrize("method,with_lstm,head_size,per_request", [
+    ("suffix", False, 128, False), ("arctic", True, 128, False), ("arctic", True, 64, False), ("arctic", True, 128, True)])
+def test_engine_steps_match_oracle_policy(method, with_lstm, head_size, per_request):
+    """per_request=False is the reference's rule: a step in which suffix decoding takes ANY request gives no draft-model
+    proposal to the others (model_runner.py:616-618); True is this build's extension (SpecConfig.draft_model_per_request)."""
     from arcticinference_amd.workload import TokenSource
     from arcticinference_amd.vllm_plugin.runner_logic import MAX_SPEC_LEN
-    eng, spec = _build(method, with_lstm, head_size)
+    eng, spec = _build(method, with_lstm, head_size, per_request)
     src = TokenSource(vocab_size=2000, seed=3, n_motifs=3, motif_min=8, motif_max=16, p_motif=0.9)
     B, PL = 4, 96
     streams = {r: src.stream(PL + 200, r) for r in range(B)}
@@ -45,7 +49,7 @@ def test_engine_steps_match_oracle_policy(method, with_lstm, head_size):
         return s[len(req.tokens):len(req.tokens) + n]
 
     min_score = 0 if method == "suffix" else spec.num_speculative_tokens
-    used_suffix = used_long = 0
+    used_suffix = used_long = used_lstm = 0
     for step in range(30):
         before = [len(r.tokens) for r in eng.requests]
         drafts_before = [list(r.drafts) for r in eng.requests]
@@ -64,18 +68,21 @@ def test_engine_steps_match_oracle_policy(method, with_lstm, head_size):
             assert len(toks) == want_acc + 1
             orc.update_response(r.req_id, toks)
         # the reference updates the cache for the whole batch first (_update_suffix_cache), then proposes
+        wants = [orc.speculate(r.req_id, r.tokens[-64:], max_spec_tokens=min(MAX_SPEC_LEN, 64, 400 - len(r.tokens) - 1))
+                 for r in eng.requests]
+        takes = [bool(w.score >= min_score and w.token_ids) for w in wants]
         for i, r in enumerate(eng.requests):
-            row = r.tokens
-            want = orc.speculate(r.req_id, row[-64:], max_spec_tokens=min(MAX_SPEC_LEN, 64, 400 - len(row) - 1))
-            if want.score >= min_score and want.token_ids:
-                assert r.drafts == want.token_ids, (step, i)
+            if takes[i]:
+                assert r.drafts == wants[i].token_ids, (step, i)
                 used_suffix += 1
-                used_long += len(want.token_ids) > 3
-            elif with_lstm:
+                used_long += len(wants[i].token_ids) > 3
+            elif with_lstm and (per_request or not any(takes)):
                 assert len(r.drafts) == 3          # LSTM drafts (values checked in test_gpu_kernels)
+                used_lstm += 1
             else:
                 assert r.drafts == []
     assert used_suffix > 10 and used_long > 0, (used_suffix, used_long)
+    assert used_lstm > 0 or not with_lstm
     st = eng.stats
     assert st.emitted == sum(len(r.tokens) - 97 for r in eng.requests)
     assert st.accepted <= st.drafted and st.num_drafts > 0

@@ -124,3 +124,35 @@ def test_cache_tree_mode_matches_oracle():
             ra = a.speculate(0, pat, 8, 2.0, 0.0, 0.05, use_tree_spec=True)
             rb = b.speculate(0, pat, 8, 2.0, 0.0, 0.05, use_tree_spec=True)
             gu.assert_cand(ra, gu.cand_dict(rb))
+
+
+def test_async_prompt_build_equals_synchronous_calls():
+    """cache_prompt_async(prompt, response) must leave exactly the trees that cache_prompt + update_response leave:
+    same global-tree image (the response enters it in call order), same prompt-tree image, also when the request is
+    extended, queried (export joins the build) or evicted while other builds are in flight."""
+    import numpy as np
+    from arcticinference_amd.workload import TokenSource
+    src = TokenSource(vocab_size=500, seed=9, n_motifs=4, motif_min=6, motif_max=12)
+    a, b = SuffixCache(16), SuffixCache(16)
+    streams = [src.stream(700, r) for r in range(6)]
+    for r in range(6):
+        a.cache_prompt(r, streams[r][:600])
+        a.update_response(r, streams[r][600:600 + r + 1])
+        b.cache_prompt_async(r, streams[r][:600], streams[r][600:600 + r + 1])
+        assert b.has_cached_prompt(r)
+        with pytest.raises(ValueError):
+            b.cache_prompt_async(r, [1, 2])
+    for c in (a, b):
+        c.update_responses([0, 3], np.asarray([7, 8, 9], np.int32), np.asarray([2, 1], np.int32))
+        c.evict_prompt(4)
+    for r in (0, 1, 2, 3, 5):
+        ea, eb = a._prompt_tree(r).export(), b._prompt_tree(r).export()
+        assert all(np.array_equal(ea[k], eb[k]) for k in ea), r
+        assert b._prompt_tree(r).selfcheck() == 0
+    ga, gb = a._global_tree().export(), b._global_tree().export()
+    assert all(np.array_equal(ga[k], gb[k]) for k in ga)
+    # a cache destroyed while builds are in flight joins them
+    c = SuffixCache(64)
+    for r in range(4):
+        c.cache_prompt_async(r, src.stream(3000, 10 + r))
+    del c
