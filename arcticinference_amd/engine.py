@@ -65,6 +65,9 @@ class StepStats:
     drafted: int = 0
     num_drafts: int = 0
     suffix_used: int = 0
+    steps: int = 0
+    draft_model_steps: int = 0      # steps whose draft-model proposal was used
+    draft_model_dropped: int = 0    # steps whose draft-model proposal was enqueued and then dropped (suffix decoding won)
 
 
 class _PendingDrafts:
@@ -388,11 +391,14 @@ class HotPathEngine:
         self._suffix_won_last = suffix_won
         if use_lstm and not spec.draft_model_per_request:
             if suffix_won:
+                self.stats.draft_model_dropped += lstm_out is not None
                 lstm_out = None                       # model_runner.py:616-618: no draft-model proposal this step
             elif lstm_out is None:
                 lstm_out = self.drafter.generate_proposals(rej.last_token, self.hidden, spec.num_speculative_tokens,
                                                            hidden_index=rej.hidden_index)
         pend = None
+        self.stats.steps += 1
+        self.stats.draft_model_steps += lstm_out is not None
         if lstm_out is not None:
             if not hasattr(self, "_lstm_pin"):
                 self._lstm_pin = [torch.empty(self.max_num_seqs, lstm_out.shape[1], dtype=lstm_out.dtype).pin_memory()

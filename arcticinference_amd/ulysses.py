@@ -143,6 +143,10 @@ def _hip_unpack(c, sp):
     return ops.ulysses_unpack_out(c, sp)
 
 
+# the copy kernels a UlyssesAttention uses unless told otherwise; CPU (gloo) tests put torch expressions here
+PACK_FNS = [_hip_pack, _hip_unpack]
+
+
 class UlyssesAttention:
     """pack -> all-to-all -> `attn` on (all tokens x local heads) -> all-to-all -> unpack (ulysses.py:491-519).
 
@@ -157,11 +161,11 @@ class UlyssesAttention:
     ag_group, ag_size)`; the copies of this variant are torch expressions (decode-size tensors)."""
 
     def __init__(self, sp_size: int, group, num_q_heads_local: int, num_kv_heads_local: int, head_size: int,
-                 pack: Callable = _hip_pack, unpack: Callable = _hip_unpack, all_to_all: Optional[Callable] = None,
+                 pack: Optional[Callable] = None, unpack: Optional[Callable] = None, all_to_all: Optional[Callable] = None,
                  kv_groups: Optional[tuple] = None, all_gather: Optional[Callable] = None):
         self.sp_size, self.group = sp_size, group
         self.hq, self.hkv, self.D = num_q_heads_local, num_kv_heads_local, head_size
-        self.pack, self.unpack = pack, unpack
+        self.pack, self.unpack = pack or PACK_FNS[0], unpack or PACK_FNS[1]
         # `all_to_all(recv, send[, group])`: torch.distributed over the SP group unless a stand-in is injected (the
         # single-GPU shape rehearsal of bench.py --rehearse-sp copies send to recv)
         self._a2a = all_to_all
@@ -310,43 +314,8 @@ class UlyssesContext:
 
 
 # --------------------------------------------------------------------------------------------------
-# vLLM patches (built only when vLLM is importable)
+# vLLM patches: arcticinference_amd/vllm_plugin/ulysses.py (built only when vLLM is importable)
 # --------------------------------------------------------------------------------------------------
 def build_ulysses_patches():
-    """ArcticPatch classes for vllm.attention.layer.Attention and ModelConfig head counts.  The executor /
-    parallel_state patches of the reference (ulysses.py:107-424) are process-management code outside the
-    hot path and are not rebuilt here; with them absent the plugin supports SP only when vLLM itself is
-    launched with a world of PP*TP*SP workers by an external launcher."""
-    from vllm.attention.layer import Attention
-    from vllm.distributed import parallel_state
-
-    from .patching import ArcticPatch
-
-    class UlyssesAttentionPatch(ArcticPatch[Attention]):
-        _orig_init = Attention.__init__
-        _orig_forward = Attention.forward
-
-        def __init__(self, num_heads, *args, **kwargs):
-            sp = getattr(parallel_state, "_SP", None)
-            self.sp_size = sp.world_size if sp is not None else 1
-            self.sp_device_group = sp.device_group if sp is not None else None
-            self._kv_groups = None
-            if self.sp_size > 1:
-                lh = local_heads(num_heads * 1, kwargs["num_kv_heads"], self.sp_size)
-                if lh.kv_replicated:
-                    # fewer kv heads than SP ranks: the SP_AA / SP_AG groups of the parallel-state patch (:437-451)
-                    aa, ag = getattr(parallel_state, "_SP_AA", None), getattr(parallel_state, "_SP_AG", None)
-                    assert aa is not None and ag is not None, "KV-replicated Ulysses needs the SP_AA and SP_AG groups"
-                    self._kv_groups = (aa.device_group, aa.world_size, ag.device_group, ag.world_size)
-                num_heads //= self.sp_size
-                kwargs["num_kv_heads"] = lh.num_kv_heads
-            return self._orig_init(num_heads, *args, **kwargs)
-
-        def forward(self, query, key, value, **kwargs):
-            if self.sp_size == 1:
-                return self._orig_forward(query, key, value, **kwargs)
-            ua = UlyssesAttention(self.sp_size, self.sp_device_group, self.num_heads, self.num_kv_heads, self.head_size,
-                                  kv_groups=self._kv_groups)
-            return ua.forward(query, key, value, lambda q_, k_, v_: self._orig_forward(q_, k_, v_, **kwargs))
-
-    return [UlyssesAttentionPatch]
+    from .vllm_plugin.ulysses import build_ulysses_patches as build
+    return build()

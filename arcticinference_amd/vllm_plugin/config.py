@@ -62,13 +62,17 @@ class ArcticSpeculativeSettings:
             self.num_speculative_tokens = self.suffix_cache_max_depth
 
 
-def build_config_patches():
-    """ArcticPatch subclasses for vLLM's config classes; call only when vLLM is importable."""
+_classes = None
+
+
+def _config_classes():
+    """ArcticParallelConfig / ArcticSpeculativeConfig (config.py:27-62), subclasses of vLLM's dataclasses."""
+    global _classes
+    if _classes is not None:
+        return _classes
     import dataclasses
 
-    from vllm.config import ParallelConfig, SpeculativeConfig, VllmConfig
-
-    from ..patching import ArcticPatch
+    from vllm.config import ParallelConfig, SpeculativeConfig
 
     @dataclasses.dataclass
     class ArcticParallelConfig(ParallelConfig):
@@ -97,6 +101,23 @@ def build_config_patches():
         suffix_max_spec_offset: float = 0.0
         suffix_min_token_prob: float = 0.1
 
+    _classes = (ArcticParallelConfig, ArcticSpeculativeConfig)
+    return _classes
+
+
+def arctic_parallel_config_class():
+    return _config_classes()[0]
+
+
+def build_config_patches():
+    """ArcticPatch subclasses for vLLM's config classes; call only when vLLM is importable."""
+    from vllm.config import ParallelConfig, SpeculativeConfig, VllmConfig
+    from vllm.transformers_utils.configs.mlp_speculator import MLPSpeculatorConfig
+
+    from ..patching import ArcticPatch
+
+    ArcticParallelConfig, ArcticSpeculativeConfig = _config_classes()
+
     class ParallelConfigPatch(ArcticPatch[ParallelConfig]):
         def __new__(cls, *args, **kwargs):
             if cls is ParallelConfig:
@@ -115,6 +136,7 @@ def build_config_patches():
         def __post_init__(self):
             use_suffix = self.method == "suffix" or (self.method is None and self.enable_suffix_decoding)
             if (use_suffix or self.method == "arctic") and self.disable_by_batch_size is None:
+                logger.info("Defaulting disable_by_batch_size to 64")
                 self.disable_by_batch_size = 64
             if use_suffix:
                 self.method = "suffix"
@@ -140,4 +162,11 @@ def build_config_patches():
                     f", enable_shift_parallel={pc.enable_shift_parallel}"
                     f", shift_parallel_threshold={pc.shift_parallel_threshold}")
 
-    return [ParallelConfigPatch, SpeculativeConfigPatch, VllmConfigPatch]
+    class MLPSpeculatorConfigPatch(ArcticPatch[MLPSpeculatorConfig]):
+        _orig_init = MLPSpeculatorConfig.__init__
+
+        def __init__(self, *args, **kwargs):
+            self.base_model_arch = kwargs.pop("base_model_arch", "")     # config.py:128-133
+            self._orig_init(*args, **kwargs)
+
+    return [ParallelConfigPatch, SpeculativeConfigPatch, VllmConfigPatch, MLPSpeculatorConfigPatch]

@@ -32,8 +32,11 @@ def arctic_inference_plugin() -> None:
         logger.warning("ArcticInference only supports vLLM V1, but detected V0 engine. Ignoring plugin!")
         return
     from .. import _native
+    # a missing library raises here (there is no CPU fallback to degrade to); a process without a visible GPU (vLLM's
+    # API-server front end loads general plugins too) still gets the argument / config patches — compute entry points
+    # answer AIC_ERR_NO_DEVICE there
     if _native.lib().aic_device_count() <= 0:
-        raise RuntimeError("libarctic_hip.so found no HIP device; there is no CPU fallback")
+        logger.warning("ArcticInference (MI355X build): no HIP device visible in this process; kernels will refuse to run")
 
     from vllm import ModelRegistry
     ModelRegistry.register_model("ArcticMLPSpeculatorPreTrainedModel",
@@ -43,11 +46,14 @@ def arctic_inference_plugin() -> None:
     ModelRegistry.register_model("MLPVariantSpeculatorPreTrainedModel",
                                  "arcticinference_amd.vllm_plugin.model_runner:ArcticLSTMSpeculatorForVllm")
 
+    from .args import build_args_patches
     from .config import build_config_patches
     from .model_runner import build_bootstrap_patches
     from .stats import build_stats_patches
-    from ..ulysses import build_ulysses_patches
+    from .ulysses import build_ulysses_patches
 
-    for patch in (build_bootstrap_patches() + build_config_patches() + build_stats_patches() +
+    # same order as the reference (plugins.py:111-126): bootstrap, arguments / configs / stats, then the Ulysses set.
+    # The GPUModelRunner patch is applied by WorkerBasePatch inside each worker, after the fork.
+    for patch in (build_bootstrap_patches() + build_args_patches() + build_config_patches() + build_stats_patches() +
                   build_ulysses_patches()):
         patch.apply_patch()

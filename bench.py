@@ -10,10 +10,16 @@ The target model's dense layers (vLLM's, not part of this path) are represented 
 of their real shapes; the synthetic target is greedy and follows a seeded ground-truth stream, so
 draft acceptance is scored model-free exactly like the reference's simulator.
 
+The batch is in STEADY STATE: the B requests start at generated positions spread evenly over 0..gen_len-1, so
+requests finish (and are replaced by fresh ones, prompt-tree build included) inside the timed region at the
+rate a long run would see, contexts average prompt + gen/2, and the response trees are populated.
+
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
-N > 1 (launched by torch.distributed.run): Ulysses sequence parallelism over the N ranks (heads sharded,
-all-to-all around attention over RCCL, vocab-parallel draft LM head); the global batch is fixed, so
-scaling is "strong".  Rank 0 prints ONE JSON line.
+N > 1: Ulysses sequence parallelism over the N ranks (heads sharded, all-to-all around attention over RCCL,
+vocab-parallel draft LM head); the global batch is fixed, so scaling is "strong".  Launched by
+torch.distributed.run (WORLD_SIZE set) the process is one rank; started plainly with --gpus N > 1 it starts
+the N ranks itself (a child `python -m torch.distributed.run`, before anything here touches the GPU) and
+exits with their code.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -49,6 +55,9 @@ def parse_args():
     ap.add_argument("--no-lstm", action="store_true")
     ap.add_argument("--kv-dtype", default="auto", choices=["auto", "fp8"], help="KV cache dtype (auto = bf16, the headline config)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--draft-model-per-request", action="store_true",
+                    help="extension: requests that suffix decoding did not take still get the draft model's proposal in "
+                         "steps where it took others (the reference gives the whole batch none, model_runner.py:616-618)")
     ap.add_argument("--no-shift-parallel", action="store_true",
                     help="N > 1: keep every step on the Ulysses all-to-all path (default: shift parallelism on, threshold "
                          "512 tokens, the reference's --enable-shift-parallel / --shift-parallel-threshold)")
@@ -62,74 +71,131 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(args, src, shape, spec):
-    """The oracle (CPU restatements; kind "port") timed on this box's host cores on a bounded sample of
-    the same workload: 2 requests, one engine step each way (suffix oracle update+speculate per request,
-    torch-CPU verify attention for 2 of the 32 layers scaled x16, greedy rejection on [6, V] logits,
-    LSTM draft with Ds=H=4096 and the full 128256-row head).  Reported beside the GPU number only."""
+def _reference_tree_class():
+    """The REAL reference suffix tree, if its compiled module travelled with the repo (oracle/_ref/_C*.so, built in the
+    build container by oracle/Makefile from the reference's own sources; never in git).  None otherwise."""
+    import glob
+    import importlib.util
+    so = glob.glob(os.path.join(ROOT, "oracle", "_ref", "_C*.so"))
+    if not so:
+        return None
+    try:
+        spec = importlib.util.spec_from_file_location("_C", so[0])
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod.SuffixTree
+    except Exception:
+        return None
+
+
+def cpu_baseline(args, src, shape, spec, run_stats):
+    """The same engine step on this box's host cores, bounded sample, checker code only (oracle/): reported beside
+    the GPU number, never part of it.
+      * verify attention: torch-CPU scaled_dot_product_attention, ALL B requests batched, bf16, GQA folded into
+        the query rows (the fastest CPU form found: K/V are read once per kv head), 2 of the L layers, scaled;
+      * acceptance: arg-max over the [B*k, V] bf16 logits (torch-CPU);
+      * suffix proposer: the reference's own suffix tree (oracle/_ref, kind "reference") when its compiled module is
+        present, else the C++ restatement (oracle/liboracle_suffix.so), under the SuffixCache policy restatement:
+        B prompt trees built, then update_response + speculate for all B requests per step;
+      * draft model: the torch-CPU bf16 op sequence (oracle.spec_oracle.lstm_generate_proposals) at B rows, weighted by
+        the share of steps that used the draft model in the GPU run.
+    Tokens per request-step are the GPU run's (identical policy, bit-exact suffix proposer)."""
+    import torch.nn.functional as F
     from oracle import spec_oracle as O
-    from oracle.suffix_oracle import OracleSuffixCache
+    from oracle.suffix_oracle import OracleSuffixCache, OracleSuffixTree
     t_all = time.perf_counter()
-    nreq, k = 2, spec.num_speculative_tokens
+    B, k = args.batch, spec.num_speculative_tokens
     threads = torch.get_num_threads()
     g = torch.Generator().manual_seed(0)
-    D, Hq, Hkv, bs = shape.head_size, shape.num_q_heads, shape.num_kv_heads, shape.block_size
-    ctx = args.prompt_len + 64
-    nblk = (ctx + bs - 1) // bs
-    kc = torch.randn(nreq * nblk, bs, Hkv, D, generator=g).to(torch.bfloat16)
-    vc = torch.randn(nreq * nblk, bs, Hkv, D, generator=g).to(torch.bfloat16)
-    bt = torch.arange(nreq * nblk, dtype=torch.int32).view(nreq, nblk)
-    q = torch.randn(nreq * (k + 1), Hq, D, generator=g).to(torch.bfloat16)
-    qsl = np.arange(nreq + 1, dtype=np.int32) * (k + 1)
+    D, Hq, Hkv = shape.head_size, shape.num_q_heads, shape.num_kv_heads
+    G = Hq // Hkv
+    S = args.prompt_len + args.gen_len // 2
+    ql = k + 1
+    # (contents do not matter for the timing: a 4-request random block tiled to B keeps the sample's set-up short)
+    tile = lambda t: t.repeat((B + t.shape[0] - 1) // t.shape[0], *([1] * (t.dim() - 1)))[:B].contiguous()
+    kc = tile(torch.randn(4, Hkv, S, D, generator=g).to(torch.bfloat16))
+    vc = tile(torch.randn(4, Hkv, S, D, generator=g).to(torch.bfloat16))
+    q = torch.randn(B, Hkv, G * ql, D, generator=g).to(torch.bfloat16)          # rows (g, position) of a kv head
+    pos = torch.arange(ql).unsqueeze(1) + (S - ql)
+    mask = (torch.arange(S).unsqueeze(0) <= pos).repeat(G, 1)
+    F.scaled_dot_product_attention(q[:2], kc[:2], vc[:2], attn_mask=mask)       # warm the thread pool
     layers_sample = 2
     t0 = time.perf_counter()
     for _ in range(layers_sample):
-        O.verify_attention(q, kc, vc, bt, [ctx] * nreq, qsl, D ** -0.5)
+        F.scaled_dot_product_attention(q, kc, vc, attn_mask=mask)
     t_attn = (time.perf_counter() - t0) * (shape.num_layers / layers_sample)
-    logits = torch.randn(nreq * k, shape.vocab_size, generator=g).to(torch.bfloat16)
+    del kc, vc
+    logits = torch.randn(8, shape.vocab_size, generator=g).to(torch.bfloat16).repeat((B * k + 7) // 8, 1)[:B * k].contiguous()
     t0 = time.perf_counter()
-    O.rejection_greedy(logits, [1] * (nreq * k), [k] * nreq, [0] * nreq, k)
+    torch.argmax(logits, dim=-1)
     t_rej = time.perf_counter() - t0
-    # suffix oracle: prompt trees + a few steps
-    cache = OracleSuffixCache(spec.suffix_cache_max_depth)
-    rows = []
-    for r in range(nreq):
-        p, gt = src.request(10_000 + r, args.prompt_len, 64)
-        cache.cache_prompt(r, [int(x) for x in p])
-        rows.append(([int(x) for x in p], [int(x) for x in gt]))
+    del logits
+    # suffix proposer
+    ref_tree = _reference_tree_class()
+    cache = OracleSuffixCache(spec.suffix_cache_max_depth, tree_cls=ref_tree or OracleSuffixTree)
+    rows = [[int(x) for x in src.stream(args.prompt_len + 160, 50_000 + r)] for r in range(B)]
     t0 = time.perf_counter()
-    n_sfx_steps = 16
+    for r in range(B):
+        cache.cache_prompt(r, rows[r][:args.prompt_len])
+    t_prompt = (time.perf_counter() - t0) / B
+    n_sfx_steps = 8
+    t0 = time.perf_counter()
     for stp in range(n_sfx_steps):
-        for r in range(nreq):
-            p, gt = rows[r]
-            cache.update_response(r, gt[2 * stp:2 * stp + 2])
-            cache.speculate(r, (p + gt[:2 * stp + 2])[-64:], max_spec_tokens=32)
+        for r in range(B):
+            e = args.prompt_len + 2 * stp + 2
+            cache.update_response(r, rows[r][e - 2:e])
+            cache.speculate(r, rows[r][e - 64:e], max_spec_tokens=32)
     t_sfx = (time.perf_counter() - t0) / n_sfx_steps
-    # LSTM oracle (bf16 head on the CPU), Ds = H = 4096, V = 128256
+    del cache
+    # draft model
     t_lstm = 0.0
+    lstm_share = run_stats["draft_model_steps"] / max(run_stats["steps"], 1)
     if not args.no_lstm:
         from arcticinference_amd.speculator import LSTMSpeculatorConfig, random_lstm_weights
         cfg = LSTMSpeculatorConfig(vocab_size=shape.vocab_size, input_hidden_dim=shape.hidden_size)
-        w = O.merge_lstm_checkpoint(random_lstm_weights(cfg, seed=0))
-        hid = torch.randn(nreq, shape.hidden_size, generator=g).to(torch.bfloat16)
+        w = O.merge_lstm_checkpoint(run_stats.get("lstm_checkpoint") or random_lstm_weights(cfg, seed=0))
+        hid = torch.randn(B, shape.hidden_size, generator=g).to(torch.bfloat16)
         t0 = time.perf_counter()
-        O.lstm_generate_proposals(w, torch.tensor([1, 2]), hid, k, cfg.n_predict, True)
+        O.lstm_generate_proposals(w, torch.arange(B), hid, k, cfg.n_predict, True)
         t_lstm = time.perf_counter() - t0
-    step_s = t_attn + t_rej + t_sfx + t_lstm
-    # tokens emitted per request-step on this workload are measured by the GPU run; use 1 + accept rate later
-    return {"step_seconds_2req": step_s, "parts_s": {"attention": t_attn, "rejection": t_rej, "suffix": t_sfx,
-                                                     "lstm": t_lstm},
-            "cores": threads, "sample_wall_s": time.perf_counter() - t_all, "nreq": nreq}
+    repl = run_stats["replacements_per_step"]
+    step_s = t_attn + t_rej + t_sfx + t_lstm * lstm_share + t_prompt * repl
+    return {"step_seconds": step_s,
+            "parts_s": {"attention_32_layers": t_attn, "rejection": t_rej, "suffix_update_and_speculate": t_sfx,
+                        "draft_model_x_share": t_lstm * lstm_share, "draft_model_one_call": t_lstm,
+                        "prompt_tree_build_x_rate": t_prompt * repl, "prompt_tree_build_one": t_prompt},
+            "suffix_tree": "reference (oracle/_ref, compiled from the reference's sources)" if ref_tree else
+                           "port (oracle/suffix_tree_oracle.cpp)",
+            "cores": threads, "sample_wall_s": time.perf_counter() - t_all}
+
+
+def spawn_ranks(args) -> int:
+    """`bench.py --gpus N` without a launcher: start N ranks as a CHILD process tree (never an exec: this process has
+    not touched the GPU, and must not before the children exist) and hand back their exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the hot path)"
+    if args.dist_backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"--gpus {world} over RCCL needs {world} visible GPUs, found {torch.cuda.device_count()} "
+                         "(use --dist-backend gloo for a rehearsal on fewer)")
     if args.dist_backend == "gloo":
         local_rank %= torch.cuda.device_count()      # rehearsal: ranks may share a device
     torch.cuda.set_device(local_rank)
@@ -142,6 +208,7 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(dev))
         else:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        assert dist.get_world_size() == world   # n_gpus below is the size of the group that really formed
 
     from arcticinference_amd import _native as N
     from arcticinference_amd.engine import HotPathEngine, ModelShape, SpecConfig
@@ -149,7 +216,7 @@ def main():
     from arcticinference_amd.workload import TokenSource
 
     shape = ModelShape(num_layers=args.layers)
-    spec = SpecConfig()
+    spec = SpecConfig(draft_model_per_request=args.draft_model_per_request)
     B, PL, GL = args.batch, args.prompt_len, args.gen_len
     max_model_len = PL + GL + 64
     src = TokenSource(seed=args.seed)
@@ -167,12 +234,15 @@ def main():
         ulysses = UlyssesContext(args.rehearse_sp, 0, None, shape, device=dev, all_to_all=lambda recv, send: recv.copy_(send),
                                  enable_shift_parallel=not args.no_shift_parallel, shift_parallel_threshold=512)
 
-    drafter = None
+    drafter = lstm_ckpt = None
     if not args.no_lstm:
         cfg = LSTMSpeculatorConfig(vocab_size=shape.vocab_size, input_hidden_dim=shape.hidden_size)
         drafter = ArcticLSTMSpeculator(cfg, max_num_seqs=B, tp_size=world, tp_rank=rank, tp_group=tp_group, device=dev,
                                        quantize_lm_head=True)
-        drafter.load_weights(random_lstm_weights(cfg, seed=args.seed).items())
+        lstm_ckpt = random_lstm_weights(cfg, seed=args.seed)
+        drafter.load_weights(lstm_ckpt.items())
+        if rank != 0 or world > 1 or args.no_cpu_baseline:
+            lstm_ckpt = None            # rank 0 of a single-GPU run keeps the host copy for the cpu_baseline leg
 
     eng = HotPathEngine(shape, spec, B, max_model_len, drafter, device=dev, ulysses=ulysses, seed=args.seed,
                         kv_cache_dtype=args.kv_dtype)
@@ -181,14 +251,21 @@ def main():
     streams = {}
     next_id = [0]
 
-    def new_request():
+    # the synthetic token source is workload GENERATION, not the path: streams for the live requests and for every
+    # replacement the run can need are drawn before the timed region
+    n_pool = B + int((args.steps + args.warmup + 16) * B * 2.0 / GL) + 8
+    pool = [src.stream(PL + GL + 128, rid) for rid in range(n_pool)]
+
+    def new_request(generated: int = 0):
+        """A fresh request; `generated` > 0 admits it mid-generation (its first `generated` + 1 response tokens exist)."""
         rid = next_id[0]
         next_id[0] += 1
-        s = src.stream(PL + GL + 128, rid)
+        s = pool[rid] if rid < n_pool else src.stream(PL + GL + 128, rid)
         streams[rid] = s
-        return rid, s[:PL], int(s[PL])
+        return rid, s[:PL], s[PL:PL + generated + 1]
 
-    first = [new_request() for _ in range(B)]
+    # steady state from step 0: request i has already generated i * GL / B tokens
+    first = [new_request((i * GL) // B) for i in range(B)]
     eng.add_requests(list(range(B)), [f[0] for f in first], [f[1] for f in first], [f[2] for f in first])
 
     def truth(r, n):
@@ -197,6 +274,7 @@ def main():
         return s[p:p + n]
 
     gen_tokens = [0]
+    replaced = [0]
 
     def run_step():
         emitted = eng.step(truth)
@@ -209,7 +287,8 @@ def main():
             if done >= GL:
                 streams.pop(r.req_id, None)
                 rid, prompt, ft = new_request()
-                eng.add_request(slot, rid, prompt, ft)   # includes the prompt-tree build (model_runner.py:664-671)
+                eng.add_request(slot, rid, prompt, ft)   # prompt tree of the new request (model_runner.py:664-671)
+                replaced[0] += 1
 
     def barrier():
         if dist is not None:
@@ -221,6 +300,7 @@ def main():
     barrier()
     N.lib().aic_profile_enable(0 if os.environ.get("AIC_BENCH_NOPROFILE") else PROFILE_STRIDE)
     gen_tokens[0] = 0
+    replaced[0] = 0
     eng.stats = type(eng.stats)()
     eng.timeline = {}
     if ulysses is not None:
@@ -249,6 +329,7 @@ def main():
         elapsed = float(t.item())
     import copy
     gen_total, stats_snapshot, timeline_snapshot = gen_tokens[0], copy.copy(eng.stats), dict(eng.timeline)
+    replaced_total = replaced[0]
     steps_shift = ulysses.steps_shift if ulysses is not None else 0
     steps_sp = ulysses.steps_sp if ulysses is not None else 0
 
@@ -278,23 +359,36 @@ def main():
         avg_launch_us = tot_us.value / max(launches.value, 1)
         bytes_per_launch = attn_bytes[0] / max(args.steps * shape.num_layers, 1)   # every launch of a step moves the same bytes
         achieved = bytes_per_launch / (avg_launch_us * 1e-6) / 1e9 if launches.value else 0.0
-        # PMC-measured HBM bytes per launch (profiles/r01_pmc_attention.json, tools/pmc_summary.py): recorded for the
-        # default single-GPU workload only; any other shape reports null rather than a number that is not its own
-        traffic = None
+        # PMC-measured HBM bytes per launch: NOT measured in this run (counters need their own rocprofv3 --pmc passes) —
+        # taken from the committed summary of those passes over this same command, and only for the workload they were
+        # collected on; any other shape reports null rather than a number that is not its own
+        traffic = traffic_source = None
         default_shape = (world == 1 and args.rehearse_sp <= 1 and args.kv_dtype == "auto" and B == 64 and PL == 4096
                          and GL == 256 and shape.num_layers == 32 and not args.no_lstm)
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_attention.json")
-        if default_shape and os.path.exists(pmc):
-            try:
-                with open(pmc) as f:
-                    traffic = json.load(f).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        for name in ("r02_pmc_attention.json", "r01_pmc_attention.json"):
+            pmc = os.path.join(ROOT, "profiles", name)
+            if default_shape and os.path.exists(pmc):
+                try:
+                    with open(pmc) as f:
+                        traffic = json.load(f).get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/" + name + " (separate rocprofv3 --pmc passes, tools/pmc_summary.py; not this run)"
+                    break
+                except Exception:
+                    traffic = None
+        golden_accept = None
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", "suffix_replay.json")) as f:
+                gr = json.load(f)[-1]
+            golden_accept = {"avg_accept_toks": gr["avg_accept_toks"], "sum_accept": gr["sum_accept"], "steps": gr["steps"],
+                             "what": "the compiled reference's suffix proposer alone (method \"suffix\": every draft taken), "
+                                     "one request at a time, same token source: tests/golden/suffix_replay.json"}
+        except Exception:
+            pass
         line = {
             "metric": "gen tokens/sec/GPU + mean accepted draft len, Llama-3.1-8B spec-decode SP=1/8",
             "value": value,
             "unit": "tokens/s",
-            "n_gpus": world,
+            "n_gpus": (dist.get_world_size() if dist is not None else 1),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -318,12 +412,18 @@ def main():
             "steps_in_shift_mode": steps_shift, "steps_in_sp_mode": steps_sp,
             "ulysses_all_to_all_path_ms_per_step": a2a_ms,
             "mean_accepted_draft_len": st.accepted / max(st.num_drafts, 1),
+            "reference_suffix_replay": golden_accept,
+            "requests_replaced_in_timed_region": replaced_total,
+            "draft_model_policy": ("per request (extension)" if spec.draft_model_per_request else
+                                   "reference rule: no draft-model proposal in a step where suffix decoding takes a request"),
+            "steps_with_draft_model": st.draft_model_steps, "draft_model_launches_dropped": st.draft_model_dropped,
             "draft_acceptance_rate": st.accepted / max(st.drafted, 1),
             "tokens_per_request_step": st.emitted / max(args.steps * B, 1),
             "suffix_share_of_drafts": st.suffix_used / max(args.steps * B, 1),
             "host_timeline_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in timeline_snapshot.items()},
             "roofline": {"bound": "hbm", "kernel": "verify_attn_pair_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "avg_launch_us": avg_launch_us, "launches_timed": launches.value,
                          "launches": args.steps * shape.num_layers,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -333,15 +433,33 @@ def main():
                                  % PROFILE_STRIDE},
         }
         if not args.no_cpu_baseline and world == 1:
-            cb = cpu_baseline(args, src, shape, spec)
             toks_per_req_step = st.emitted / max(args.steps * B, 1)
+            cb = cpu_baseline(args, src, shape, spec, {"steps": st.steps, "draft_model_steps": st.draft_model_steps,
+                                                       "replacements_per_step": replaced_total / max(args.steps, 1),
+                                                       "lstm_checkpoint": lstm_ckpt})
+            ref_cpu = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_reference_cpu_suffix.json")) as f:
+                    rc_ = json.load(f)
+                ref_cpu = {"source": "profiles/r01_reference_cpu_suffix.json (the reference's suffix proposer alone, timed in the "
+                                     "build container on %d cores; oracle/time_reference_cpu.py)" % rc_["host"]["cpus"],
+                           "single_thread": {k_: rc_["single_thread"][k_] for k_ in
+                                             ("us_per_speculate", "us_per_updated_token", "us_per_cache_prompt_4096",
+                                              "generated_tokens_per_s", "mean_accepted_per_step")},
+                           "independent_processes_%d" % rc_["processes"]: {
+                               "generated_tokens_per_s": rc_["independent_processes"]["generated_tokens_per_s"]}}
+            except Exception:
+                pass
             line["cpu_baseline"] = {
-                "value": cb["nreq"] * toks_per_req_step / cb["step_seconds_2req"], "unit": "tokens/s",
+                "value": B * toks_per_req_step / cb["step_seconds"], "unit": "tokens/s",
                 "cores": cb["cores"], "kind": "port",
-                "sample": "oracle (CPU restatements) on 2 requests x 1 engine step: suffix update+speculate, torch-CPU "
-                          "verify attention on 2 of 32 layers (scaled x16), greedy rejection on [6, V], LSTM draft "
-                          "(Ds=4096, V=128256); tokens per request-step taken from the GPU run",
-                "parts_s": cb["parts_s"], "sample_wall_s": cb["sample_wall_s"]}
+                "sample": "one engine step of the same B=%d workload on the host cores: torch-CPU SDPA over all %d requests "
+                          "(bf16, GQA folded into the query rows, ctx %d) on 2 of %d layers scaled; arg-max acceptance on "
+                          "[%d, V]; suffix proposer = %s under the SuffixCache policy restatement, %d prompt trees + 8 steps "
+                          "of update+speculate for all requests; torch-CPU bf16 LSTM draft (Ds=4096, V=128256) at %d rows "
+                          "weighted by the share of steps that used the draft model; tokens per request-step from the GPU run"
+                          % (B, B, PL + GL // 2, shape.num_layers, B * spec.num_speculative_tokens, cb["suffix_tree"], B, B),
+                "parts_s": cb["parts_s"], "sample_wall_s": cb["sample_wall_s"], "reference_suffix_proposer_cpu": ref_cpu}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -26,3 +26,14 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture
+def stub_vllm():
+    """The stand-in for vLLM 0.9.2 (tests/stubs/README.md), freshly imported: importable as `vllm` inside the test."""
+    import vllm_harness
+    mod = vllm_harness.install()
+    try:
+        yield mod
+    finally:
+        vllm_harness.uninstall()

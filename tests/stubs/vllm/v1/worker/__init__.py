@@ -1,0 +1,1 @@
+"""tests-only stand-in package (see tests/stubs/README.md)."""

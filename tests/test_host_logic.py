@@ -154,3 +154,31 @@ def test_head_partition_and_shift_rules():
     owned = sorted(sp_tp_head_slice(32, 4, 2, s, t) for s in range(4) for t in range(2))
     assert owned == [(i * 4, i * 4 + 4) for i in range(8)]
     assert sp_tp_head_slice(32, 4, 2, sp_rank=1, tp_rank=1) == (20, 24)
+
+
+def test_bench_starts_its_own_ranks(monkeypatch):
+    """`bench.py --gpus N` without a launcher must start N ranks as a child torch.distributed.run (never an exec, and
+    before anything touches the GPU) and exit with the child's code."""
+    import subprocess
+    import sys
+
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    import torch
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("GPU touched before the spawn")))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
