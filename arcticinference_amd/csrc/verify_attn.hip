@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 #include "aic_common.h"
@@ -70,6 +71,7 @@ struct AttnParams {
   const float* v_scale;
   float sm_scale;
   int dbg;
+  int64_t* trace;  // debug (aic_debug_attn_trace): per workgroup {start, end (100 MHz ticks), HW_ID | XCC_ID << 32, kind}
 };
 
 // 16-byte load of KV bytes, non-temporal: every byte of the cache is read once per call, and with the default
@@ -664,6 +666,9 @@ __device__ __forceinline__ void long_tile_compute(const char* kb, const char* vb
       alpha[mt] = __builtin_amdgcn_exp2f(m_run[mt] - m_use[mt]);
       m_run[mt] = m_new;
     }
+    // (P as ONE bf16 operand with the row sum taken over the rounded weights — what kernels that feed P to the matrix unit
+    // in the value dtype do — was measured: long-only B=16 x 33 134 -> 103 us together with two workgroups per CU, but a
+    // 40-token context then misses the 1e-3 tolerance: few terms, nothing averages the 2^-9 weight errors out.)
     bf16x8 pfrag[NT], pfrag_lo[NT];
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
@@ -975,15 +980,31 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 verify_attn_pair_kernel(AttnParams PS, AttnParams PL, int n_long_wg, int n_long_pad, int long_x, int long_y, int short_x) {
   __shared__ uint4 lds[kLong4LdsU4 > ShortLds<MTQ, 4>::kU4 ? kLong4LdsU4 : ShortLds<MTQ, 4>::kU4];
   const int b = blockIdx.x;
+  int64_t t0 = 0;
+  if (PS.trace) t0 = static_cast<int64_t>(__builtin_amdgcn_s_memrealtime());
   if (b < n_long_pad) {
-    if (b >= n_long_wg) return;
-    const int x = b % long_x, yz = b / long_x;
-    const int y = yz % long_y, z = yz / long_y;
-    verify_attn_long4_body<KV8, 128>(PL, lds, x, y, z);
+    if (b < n_long_wg) {
+      const int x = b % long_x, yz = b / long_x;
+      const int y = yz % long_y, z = yz / long_y;
+      verify_attn_long4_body<KV8, 128>(PL, lds, x, y, z);
+    }
   } else {
     const int sb = b - n_long_pad;
     __builtin_amdgcn_s_setprio(3);   // the memory-bound short body sets the launch's end: its waves issue first
     verify_attn_body<MTQ, WH, KV8, 4>(PS, lds, sb % short_x, sb / short_x);
+  }
+  if (PS.trace) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      int64_t* r = PS.trace + static_cast<int64_t>(b) * 4;
+      r[0] = t0;
+      r[1] = static_cast<int64_t>(__builtin_amdgcn_s_memrealtime());
+      r[2] = static_cast<int64_t>(hw) | (static_cast<int64_t>(xcc) << 32);
+      r[3] = b < n_long_wg ? 1 : (b < n_long_pad ? 2 : 0);
+    }
   }
 }
 
@@ -1048,25 +1069,31 @@ struct SideStream {
   hipEvent_t fork = nullptr, join = nullptr;
   int device = -1;
 };
-static SideStream g_side;
+// one per device, created on first use and kept for the life of the process (a process drives one device in this
+// design; a caller that switches devices gets that device's own stream and events, nothing is re-created or leaked)
+static SideStream g_side[16];
 static int side_stream(SideStream** out) {
   int dev = 0;
   AIC_HIP_TRY(hipGetDevice(&dev));
-  if (g_side.stream == nullptr || g_side.device != dev) {
-    AIC_HIP_TRY(hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking));
-    AIC_HIP_TRY(hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming));
-    AIC_HIP_TRY(hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming));
-    g_side.device = dev;
+  AIC_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
+  SideStream& S = g_side[dev];
+  if (S.stream == nullptr) {
+    AIC_HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+    AIC_HIP_TRY(hipEventCreateWithFlags(&S.fork, hipEventDisableTiming));
+    AIC_HIP_TRY(hipEventCreateWithFlags(&S.join, hipEventDisableTiming));
+    S.device = dev;
   }
-  *out = &g_side;
+  *out = &S;
   return AIC_OK;
 }
 
-// Token-range splits per (request, head group) item.  Measured on MI355X (B=64, ctx 4096): what matters is
-// not occupancy but BALANCE — the grid should be an exact multiple of the 256 CUs and fit one residency round
-// (256 workgroups = one 4-wave workgroup per CU ran 190 us; 1152 workgroups = 1.5 rounds of 3 per CU 225 us),
-// and fewer splits also mean fewer partials to write and merge.  So: the smallest split count that gives every
-// CU a workgroup, rounded so the grid is a multiple of the CU count when the batch allows it.
+// Token-range splits per (request, head group) item.  Measured on MI355X (B=64, ctx 4096, 128 items): what matters
+// is not occupancy but BALANCE — 256 workgroups (one per CU) ran 171 us, 512 (two per CU) 181 us, 384 205 us, 768 197 us,
+// 1024 204 us: a grid that is not a multiple of the CU count leaves a tail in which some CUs stream a second
+// workgroup while the others idle.  With 59 requests (118 items) "one workgroup per CU at least" gave 3 splits = 354
+// workgroups and 202 us, slower than 64 requests (179 us).  pick_splits therefore scores every split count by the tail
+// it leaves — ceil(W / CUs) CU-rounds for W workgroups of equal size — plus a small charge per extra round and per
+// split (partials to write and merge), and takes the cheapest.
 // compute units of the current device (256 on an MI355X in SPX mode; fewer in a partitioned mode)
 static int cu_count() {
   static int cached = 0;
@@ -1081,31 +1108,46 @@ static int cu_count() {
   return cached;
 }
 
-static int pick_splits(int n_items, int max_seq_len, int min_tiles_per_split) {
-  static const int64_t forced = []() { const char* e = getenv("AIC_ATTN_WAVES"); return e ? atoll(e) : 0LL; }();
-  const int kCUs = cu_count();
+// `wgs_per_cu`: how many workgroups of the body should share a CU.  The short body streams: one per CU measured best.
+// The shared-tile (long-draft) body is bound by its own MFMA + VALU chain per tile and wants a second workgroup on the
+// CU to fill its stalls (alone, one wave per SIMD, it ran at 2 us per 32-token tile).
+static int pick_splits(int n_items, int max_seq_len, int min_tiles_per_split, int wgs_per_cu = 1) {
+  const int kCUs = cu_count() * wgs_per_cu;
   const int max_tiles = (max_seq_len + kTile - 1) / kTile;
   int cap = std::max(1, max_tiles / std::max(1, min_tiles_per_split));
   if (cap > 64) cap = 64;
-  int s;
-  if (forced > 0) {
-    s = static_cast<int>((forced / 4 + n_items - 1) / n_items);
-  } else if (n_items >= kCUs) {
-    s = 1;
-  } else {
-    s = (kCUs + n_items - 1) / n_items;              // >= one workgroup per CU
-    if ((n_items * s) % kCUs != 0 && n_items * (s - 1) >= kCUs * 15 / 16) --s;  // 240 of 256 CUs beats 1.2 rounds
+  int best = 1;
+  double best_cost = 1e30;
+  for (int s = 1; s <= cap; ++s) {
+    const double wgs = static_cast<double>(n_items) * s;
+    const double rounds = std::ceil(wgs / kCUs);
+    // time ~ rounds * (work per workgroup) = rounds / s; normalised by the ideal n_items / kCUs
+    const double tail = rounds * kCUs / wgs;
+    const double cost = tail * (1.0 + 0.03 * (rounds - 1.0)) + 0.004 * s;
+    if (cost < best_cost - 1e-9) {
+      best_cost = cost;
+      best = s;
+    }
   }
-  if (s > cap) s = cap;
-  if (s < 1) s = 1;
-  return s;
+  return best;
 }
 
 }  // namespace aic
 
 using namespace aic;
 
+static int64_t* g_attn_trace = nullptr;
+static int g_attn_trace_cap = 0;
+
 extern "C" {
+
+// debug: the next pair-kernel launches record per-workgroup start / end times and placement into `buf`
+// ([capacity][4] int64, device); nullptr switches it off
+int aic_debug_attn_trace(int64_t* buf, int capacity_wgs) {
+  g_attn_trace = buf;
+  g_attn_trace_cap = capacity_wgs;
+  return AIC_OK;
+}
 
 size_t aic_verify_attention_workspace_bytes(int num_tokens, int num_q_heads, int head_size, int num_splits_max) {
   const size_t rows = static_cast<size_t>(num_tokens) * num_q_heads;
@@ -1157,7 +1199,7 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
     // token range per workgroup, up to 192 rows), whatever its query length; then the combine kernel
     const size_t rows64 = static_cast<size_t>(num_tokens) * num_q_heads;
     const int items = batch * num_kv_heads;
-    int splits = pick_splits(items, max_seq_len, 4);
+    int splits = pick_splits(items, max_seq_len, 4, 2);
     auto fits64 = [&](int parts) { return static_cast<size_t>(parts) * rows64 * (64 + 2) * sizeof(float) <= workspace_bytes; };
     while (splits > 1 && !fits64(splits)) --splits;
     AIC_REQUIRE(fits64(splits), "workspace too small (%zu bytes)", workspace_bytes);
@@ -1185,6 +1227,8 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
     P.req_list = nullptr;
     P.k_scale = P.v_scale = nullptr;
     P.dbg = 0;
+    P.trace = nullptr;
+  P.trace = nullptr;
     hipStream_t s64 = static_cast<hipStream_t>(stream);
     const int rows_per_wg = 4 * kLongTilesPerWave * 16;
     const int max_rows64 = max_q_len * (num_q_heads / num_kv_heads);
@@ -1204,7 +1248,7 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   const size_t rows = static_cast<size_t>(num_tokens) * num_q_heads;
   // splits of the short / generic launch and of the long-draft launch (its items are few: more splits)
   int n_splits = pick_splits((split_lists ? std::max(n_short, 1) : batch) * hgroups, max_seq_len, wave_heads ? 2 : 8);
-  int n_splits_long = (split_lists && n_long > 0) ? pick_splits(n_long * num_kv_heads, max_seq_len, 16) : 0;
+  int n_splits_long = (split_lists && n_long > 0) ? pick_splits(n_long * num_kv_heads, max_seq_len, 8, 2) : 0;
   auto fits = [&](int parts) { return static_cast<size_t>(parts) * rows * (kD + 2) * sizeof(float) <= workspace_bytes; };
   while (n_splits > 1 && !fits(n_splits)) --n_splits;
   while (n_splits_long > 1 && !fits(n_splits_long)) --n_splits_long;
@@ -1233,9 +1277,8 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   P.req_list = nullptr;
   P.k_scale = k_scale;
   P.v_scale = v_scale;
-  // tuning switches (every setting computes the same result): AIC_ATTN_DBG bit 4 (16) = long then short on one
-  // stream, bit 5 (32) = two launches on two streams
-  P.dbg = []() { const char* e = getenv("AIC_ATTN_DBG"); return e ? atoi(e) : 0; }();
+  P.dbg = 0;
+  P.trace = nullptr;
 
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
@@ -1272,8 +1315,10 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
     const int per_block_rows_p = 4 * kLongTilesPerWave * 16;
     const int long_z = (max_rows + per_block_rows_p - 1) / per_block_rows_p;
     const int short_wg = (n_short * hgroups + 7) / 8 * 8 * n_splits;
-    // one launch for both kinds of request when every workgroup of it can be resident at once (two per CU)
-    bool pair = n_short > 0 && n_long > 0 && !(P.dbg & (16 | 32));
+    // one launch for both kinds of request when every workgroup of it can be resident at once (two per CU).  (Letting
+    // the long part take the whole chip first — 2 workgroups per CU, the short ones dispatched as those retire — was
+    // measured and is worse: 59 short + 5 long 214 us against 206 us, and the bench's real mix 267 us against 182 us.)
+    bool pair = n_short > 0 && n_long > 0;
     if (pair) {
       const int room = 2 * cu_count() - short_wg;
       const int per_split = n_long * num_kv_heads * long_z;
@@ -1295,6 +1340,7 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
       const int short_x = (P.n_items + 7) / 8 * 8;
       profile_begin(s);
       const dim3 pgrid(static_cast<unsigned>(n_long_pad + short_wg));
+      P.trace = (g_attn_trace && static_cast<int>(pgrid.x) <= g_attn_trace_cap) ? g_attn_trace : nullptr;
 #define AIC_PAIR_LAUNCH(WH_, KV8_)                                                                              \
   if (mtq_short == 1)                                                                                           \
     hipLaunchKernelGGL((verify_attn_pair_kernel<WH_, KV8_, 1>), pgrid, dim3(256), 0, s, P, PL, n_long_wg, n_long_pad, long_x, \
@@ -1311,8 +1357,8 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
       profile_end(s);
       n_short = n_long = 0;  // both done
     }
-    const bool overlap = n_short > 0 && n_long > 0 && !(P.dbg & 16);
-    static const bool short_first = []() { const char* e = getenv("AIC_ATTN_SHORT_FIRST"); return e && e[0] == '1'; }();
+    const bool overlap = n_short > 0 && n_long > 0;
+    const bool short_first = false;
     if (n_short > 0) profile_begin(s);  // bench.py's roofline figure: the short-request kernel alone (the begin
                                         // marker sits before the fork so that it delays neither kernel's start)
     if (overlap) {

@@ -411,6 +411,7 @@ class HotPathEngine:
             ev.record()
             pend = _PendingDrafts(pin, ev, [])
         self._lstm_prev = lstm_out
+        _mark('host_draft_copy')
         # the draft model's length clamp is ONE value for the batch in the reference (the running minimum of
         # propose_arctic_draft_token_ids, model_runner.py:629-641); the per-request extension clamps per request
         k_batch = spec.num_speculative_tokens

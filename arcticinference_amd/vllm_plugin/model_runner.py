@@ -523,12 +523,12 @@ def build_model_runner_patch():
                 spec_ids = spec_token_ids[i] if spec_token_ids is not None else []
                 if not sampled:
                     continue
-                start = int(ib.num_tokens_no_spec[i])
-                end = start + len(sampled)
+                # execute_model has already appended this step's sampled ids to the row and advanced num_tokens_no_spec
+                # (:469-486).  The reference adds len(sampled) to it a second time here (:698-699, :709), so its pattern
+                # ends with the sampled ids repeated; this build takes the row as it is (deviations).
+                end = int(ib.num_tokens_no_spec[i])
                 if end >= self.max_model_len:
-                    ib.token_ids_cpu[i, start:self.max_model_len] = sampled[:self.max_model_len - start]
                     continue
-                ib.token_ids_cpu[i, start:end] = sampled
                 q = suffix_query(ib.token_ids_cpu[i], end, spec_ids, self.max_model_len, cfg.suffix_cache_max_depth,
                                  cfg.suffix_max_spec_factor, cfg.suffix_max_spec_offset, cfg.suffix_min_token_prob)
                 if q is None:
@@ -557,13 +557,11 @@ def build_model_runner_patch():
                     req_id = ib.req_ids[i]
                     st = self.requests[req_id]
                     sampled = [st.get_token_id(st.num_computed_tokens + scheduler_output.num_scheduled_tokens[req_id])]
-                start = int(ib.num_tokens_no_spec[i])
-                end = start + n
+                end = int(ib.num_tokens_no_spec[i])        # the row already holds this step's sampled ids (see above)
                 k = min(k, self.max_model_len - end - 1)
                 if k <= 0:
                     continue
-                ib.token_ids_cpu[i, start:end] = sampled[-1]
-                last_tokens.append(int(ib.token_ids_cpu[i, end - 1]))
+                last_tokens.append(int(sampled[-1]))
             if k <= 0:
                 return [[] for _ in sampled_token_ids]
             early = self._arctic_early
@@ -608,7 +606,7 @@ def build_model_runner_patch():
             elif sc.method in ("arctic", "mlp_speculator"):
                 assert isinstance(self.drafter, ArcticProposer)
                 early = self._arctic_early
-                ends = [int(self.input_batch.num_tokens_no_spec[i]) + len(s) for i, s in enumerate(remaining)]
+                ends = [int(self.input_batch.num_tokens_no_spec[i]) for i in range(len(remaining))]
                 usable = (early is not None and all(len(s) > 0 for s in remaining)
                           and arctic_max_spec_tokens(sc.num_speculative_tokens, ends, self.max_model_len) == early[0])
                 prev = None

@@ -298,6 +298,12 @@ def main():
     for _ in range(args.warmup):
         run_step()
     barrier()
+    # the host side keeps ~300k long-lived Python objects (token lists of the live requests): a generation-2 garbage
+    # collection that walks them costs milliseconds and would land inside a step; they are parked in the permanent
+    # generation instead (what vLLM does after start-up)
+    import gc
+    gc.collect()
+    gc.freeze()
     N.lib().aic_profile_enable(0 if os.environ.get("AIC_BENCH_NOPROFILE") else PROFILE_STRIDE)
     gen_tokens[0] = 0
     replaced[0] = 0

@@ -148,6 +148,22 @@ int aic_sc_last_stats(const aic_suffix_cache* c, float* match_us, int64_t* mirro
 aic_suffix_tree* aic_sc_global_tree(aic_suffix_cache* c);
 aic_suffix_tree* aic_sc_prompt_tree(aic_suffix_cache* c, int64_t req);
 
+/* debug aid (tools/microbench.py trace): while `buf` is set, every launch of the one-grid short + long attention kernel
+ * records per workgroup {start, end (100 MHz ticks), HW_ID | XCC_ID << 32, kind (0 short, 1 long, 2 pad)} into
+ * buf[workgroup][4] (device int64, at least capacity_wgs rows).  NULL switches it off. */
+int aic_debug_attn_trace(int64_t* buf, int capacity_wgs);
+
+/* ------------------------------------------------------------------------------------------
+ * (f)-1  SwiftKV token selection — the index_fn gathers of LlamaSwiftKVModel.swiftkv_select
+ *      (vllm/swiftkv/llama_swiftkv.py:665-685): dst[t][i, :] = src[t][index[i], :] for up to 8 row-major 2-D tensors
+ *      (hidden states, residual, positions, k_states, v_states) in ONE launch.  Pointer / stride tables are HOST arrays
+ *      passed by value; `index` is a device int64 array (SpecDecode / sampling rows: logits_indices).  Destination rows
+ *      may be the decode runner's persistent graph buffers.  Out-of-range indices are skipped.  Graph-capture safe.
+ * ---------------------------------------------------------------------------------------- */
+int aic_row_gather(int n_tensors, const void* const* src /*host array of device ptrs*/, void* const* dst /*host*/,
+                   const int64_t* src_stride_bytes /*host*/, const int64_t* dst_stride_bytes /*host*/,
+                   const int32_t* row_bytes /*host*/, const int64_t* index /*device*/, int n_sel, int n_src_rows, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * A16  Bulk paged-KV write — replaces torch.ops.arctic_inference.reshape_and_cache_flash_bulk
  *      (csrc/custom_ops/torch_bindings.cpp:5-18, kernels.cu:12-155, py_custom_ops.py:40-54).

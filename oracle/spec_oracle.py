@@ -298,3 +298,17 @@ def all_to_all_single_emulated(per_rank_inputs: List[torch.Tensor]) -> List[torc
     sp = len(per_rank_inputs)
     chunks = [t.chunk(sp, dim=0) for t in per_rank_inputs]
     return [torch.cat([chunks[src][dst] for src in range(sp)], dim=0) for dst in range(sp)]
+
+
+# ----------------------------------------------------------------------------------------------
+# SwiftKV selection (vllm/swiftkv/llama_swiftkv.py:418-431, :573-685) — literal torch expressions
+# ----------------------------------------------------------------------------------------------
+def swiftkv_select(hidden_states, residual, positions, k_states, v_states, query_start_loc, slot_mapping, logits_indices,
+                   key_caches, value_caches, kv_cache_dtype, k_scales, v_scales, num_heads, head_size):
+    """Returns (selected five tensors, new query_start_loc, new slot_mapping); the caches are written in place."""
+    kv_bulk_write(k_states, v_states, key_caches, value_caches, slot_mapping, kv_cache_dtype, k_scales, v_scales, num_heads,
+                  head_size)
+    new_qsl = torch.searchsorted(logits_indices, query_start_loc.to(logits_indices.dtype), out_int32=True)
+    new_slots = slot_mapping[logits_indices]
+    sel = tuple(t.index_select(0, logits_indices) for t in (hidden_states, residual, positions, k_states, v_states))
+    return sel, new_qsl, new_slots

@@ -47,7 +47,12 @@ class GroupCoordinator:
 
     def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
         if self.world_size > 1:
-            dist.all_reduce(t, group=self.device_group)
+            if t.is_cuda and dist.get_backend(self.device_group) == "gloo":     # ranks sharing one GPU in tests
+                host = t.cpu()
+                dist.all_reduce(host, group=self.device_group)
+                t.copy_(host)
+            else:
+                dist.all_reduce(t, group=self.device_group)
         return t
 
     @contextmanager

@@ -1,0 +1,280 @@
+"""GPU: the patched vLLM worker end to end on the MI355X, through the stand-in for vLLM 0.9.2 (tests/stubs).
+
+With every patch applied, GPUModelRunner.execute_model is driven for a batch of requests and must
+  * route decode / verify attention to aic_verify_attention_ex (the stand-in's torch attention only sees prefills),
+  * accept with the HIP kernel (vLLM's RejectionSampler is never called for a greedy batch),
+  * emit exactly the target model's greedy tokens,
+  * propose, every step, the drafts of the reference policy: the oracle SuffixCache's result where its score reaches
+    the bar, else (method "arctic", and only in steps where suffix decoding took nobody) the LSTM speculator's tokens
+    for the hidden-state row arctic_proposer.py:133-147 selects — recomputed here from the captured hidden states.
+The target is the toy model with its logits steered along a seeded ground-truth stream (so drafts get accepted)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import vllm_harness as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+HF = dict(num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=4, hidden_size=512, head_dim=128, vocab_size=2000)
+
+
+def _vllm_config(spec=None, parallel=None, device=DEV, dtype=torch.bfloat16, level=0):
+    from vllm.config import (CacheConfig, CompilationConfig, DeviceConfig, HfConfig, ModelConfig, ParallelConfig,
+                             SchedulerConfig, VllmConfig)
+    return VllmConfig(model_config=ModelConfig(hf_config=HfConfig(**HF), max_model_len=400, dtype=dtype),
+                      parallel_config=parallel or ParallelConfig(), scheduler_config=SchedulerConfig(max_num_seqs=8),
+                      cache_config=CacheConfig(block_size=16), speculative_config=spec,
+                      compilation_config=CompilationConfig(level=level, cudagraph_capture_sizes=(64, 32, 16, 8, 4)),
+                      device_config=DeviceConfig(device))
+
+
+def _lstm_spec_config(enable_suffix=True):
+    from vllm.config import ModelConfig, ParallelConfig, SpeculativeConfig
+
+    class DraftHf:
+        architectures = ["ArcticLSTMSpeculatorPreTrainedModel"]
+        base_model_archs = ["ToyLlamaForCausalLM"]
+        vocab_size, input_hidden_dim, inner_dim, emb_dim, proj_dim = 2000, 512, "512", "512", "512"
+        n_predict = num_lookahead_tokens = 3
+        tie_weights = tie_lstm_embs = True
+        scale_input = True
+        method = "sum_lstm"
+
+    return SpeculativeConfig(method="arctic", num_speculative_tokens=3, enable_suffix_decoding=enable_suffix,
+                             draft_model_config=ModelConfig(hf_config=DraftHf()), draft_parallel_config=ParallelConfig())
+
+
+class Steered:
+    """Makes the toy model's greedy token at sequence position p + 1 the ground truth's, for every sampled row."""
+
+    def __init__(self, runner, sched, streams):
+        self.runner, self.sched, self.streams = runner, sched, streams
+        self.hidden = None
+        runner.model.logit_hook = self
+
+    def plan(self, so):
+        rows = []
+        for rid, r in self.sched.reqs.items():
+            n, k = so.num_scheduled_tokens[rid], len(so.scheduled_spec_decode_tokens.get(rid, ()))
+            last = r["computed"] + n - 1
+            rows += [(rid, p) for p in range(last - k, last + 1)]
+        self.rows = rows
+
+    def __call__(self, hidden_states, logits):
+        self.hidden = hidden_states
+        assert logits.shape[0] == len(self.rows)
+        tok = torch.tensor([int(self.streams[rid][p + 1]) for rid, p in self.rows], device=logits.device)
+        logits[torch.arange(len(self.rows), device=logits.device), tok] = 60.0
+        return logits.to(torch.bfloat16)
+
+
+def _requests(n, plen, seed):
+    from arcticinference_amd.workload import TokenSource
+    src = TokenSource(vocab_size=2000, seed=seed, n_motifs=3, motif_min=8, motif_max=16, p_motif=0.9)
+    return {f"r{i}": src.stream(plen + 260, i) for i in range(n)}
+
+
+@pytest.mark.parametrize("method", ["suffix", "arctic"])
+def test_patched_execute_model_runs_the_hip_path_and_the_reference_policy(stub_vllm, method):
+    from oracle.suffix_oracle import OracleSuffixCache
+    H.load_plugin()
+    from vllm.attention.layer import Attention
+    from vllm.config import SpeculativeConfig, set_current_vllm_config
+    from vllm.v1.sample.rejection_sampler import RejectionSampler
+    from vllm.v1.worker.gpu_model_runner import GPUModelRunner
+    from arcticinference_amd.speculator import LSTMSpeculatorConfig, random_lstm_weights
+    from arcticinference_amd.vllm_plugin import step_context
+    from arcticinference_amd.vllm_plugin.runner_logic import MAX_SPEC_LEN
+    spec = SpeculativeConfig(method="suffix") if method == "suffix" else _lstm_spec_config()
+    cfg = _vllm_config(spec)
+    H.init_single_process_groups(cfg)
+    runner = GPUModelRunner(cfg, torch.device(DEV))
+    set_current_vllm_config(cfg)
+    runner.load_model()
+    if method == "arctic":
+        lcfg = LSTMSpeculatorConfig(vocab_size=2000, input_hidden_dim=512, inner_dim="512", emb_dim="512", proj_dim="512")
+        runner.drafter.model.load_weights(random_lstm_weights(lcfg, seed=0, std=0.05).items())
+        assert runner.drafter.input_hidden_dim == 512
+    runner.initialize_kv_cache((200, torch.bfloat16))
+    B, PL, limit = 4, 96, 400
+    streams = _requests(B, PL, seed=3)
+    sched = H.MiniScheduler(16, limit)
+    for rid, s in streams.items():
+        sched.add(rid, [int(x) for x in s[:PL]])
+    steer = Steered(runner, sched, streams)
+    orc = OracleSuffixCache(64)
+    min_score = 0 if method == "suffix" else 3
+    step_context.calls.update(verify=0, fallback=0)
+    Attention.calls = RejectionSampler.calls = 0
+    used_suffix = used_lstm = long_drafts = 0
+    for step in range(28):
+        so = sched.schedule()
+        steer.plan(so)
+        out = runner.execute_model(so)
+        n_spec = {rid: len(so.scheduled_spec_decode_tokens.get(rid, ())) for rid in sched.reqs}
+        hidden = steer.hidden
+        emitted = sched.update(out)
+        at = 0
+        rows_of = {}
+        for rid in out.req_ids:
+            rows_of[rid] = at
+            at += n_spec[rid] + 1
+        for i, rid in enumerate(out.req_ids):
+            r = sched.reqs[rid]
+            seq = r["prompt"] + r["out"]
+            toks = emitted[rid]
+            assert toks == [int(x) for x in streams[rid][len(seq) - len(toks):len(seq)]], (step, rid)   # the target's tokens
+            if not orc.has_cached_prompt(rid):
+                orc.cache_prompt(rid, r["prompt"])
+            orc.update_response(rid, toks)
+        wants = {}
+        for rid in out.req_ids:
+            seq = sched.reqs[rid]["prompt"] + sched.reqs[rid]["out"]
+            wants[rid] = orc.speculate(rid, seq[-64:], max_spec_tokens=min(MAX_SPEC_LEN, 64, limit - len(seq) - 1))
+        takes = {rid: bool(w.score >= min_score) for rid, w in wants.items()}
+        lstm_want = None
+        if method == "arctic" and not any(takes.values()):
+            idx = torch.tensor([rows_of[rid] + len(emitted[rid]) - 1 for rid in out.req_ids], device=DEV)
+            last = torch.tensor([emitted[rid][-1] for rid in out.req_ids], device=DEV)
+            lstm_want = runner.drafter.model.generate_proposals(last, hidden[idx], 3).cpu().tolist()
+        for i, rid in enumerate(out.req_ids):
+            got = out.spec_token_ids[i]
+            if takes[rid]:
+                assert got == wants[rid].token_ids, (step, rid)
+                used_suffix += bool(got)
+                long_drafts += len(got) > 3
+            elif lstm_want is not None:
+                assert got == lstm_want[i], (step, rid)
+                used_lstm += 1
+            else:
+                assert got == [], (step, rid)
+    assert used_suffix > 10 and long_drafts > 0
+    assert method == "suffix" or used_lstm > 0
+    assert sched.stats["accepted"] > 0
+    # routing: 28 steps x 2 layers; only the first (prefill, 96 tokens per request) went to vLLM's attention
+    assert Attention.calls == 2 and step_context.calls["fallback"] == 2 and step_context.calls["verify"] == 27 * 2
+    assert RejectionSampler.calls == 0          # every verify step was accepted by aic_rejection_greedy
+    assert runner._suffix_cache._global_tree().selfcheck() == 0
+
+
+def test_hip_attention_route_equals_the_stand_in_backend(stub_vllm):
+    """The same request batch through vLLM's (stand-in) attention and through the plugin's HIP route: decode-step
+    outputs (last-layer hidden states of the sampled rows) agree within the kernel tolerance."""
+    from vllm.config import SpeculativeConfig, set_current_vllm_config
+    from vllm.v1.worker.gpu_model_runner import GPUModelRunner
+    streams = _requests(3, 80, seed=9)
+
+    def run(patched):
+        if patched:
+            H.install()
+            H.load_plugin()
+        from vllm.config import SpeculativeConfig, set_current_vllm_config
+        from vllm.v1.worker.gpu_model_runner import GPUModelRunner
+        cfg = _vllm_config(SpeculativeConfig(method="ngram", num_speculative_tokens=2))
+        H.init_single_process_groups(cfg)
+        r = GPUModelRunner(cfg, torch.device(DEV))
+        set_current_vllm_config(cfg)
+        r.load_model()
+        r.initialize_kv_cache((200, torch.bfloat16))
+        sched = H.MiniScheduler(16, 400)
+        for rid, s in streams.items():
+            sched.add(rid, [int(x) for x in s[:80]])
+        steer = Steered(r, sched, streams)
+        hs = []
+        for _ in range(6):
+            so = sched.schedule()
+            steer.plan(so)
+            sched.update(r.execute_model(so))
+            hs.append(steer.hidden.float().cpu())
+        return hs
+
+    a = run(False)
+    b = run(True)
+    from arcticinference_amd.vllm_plugin import step_context
+    assert step_context.calls["verify"] >= 10
+    for x, y in zip(a, b):
+        assert x.shape == y.shape
+        assert torch.allclose(x, y, atol=3e-2, rtol=3e-2), (x - y).abs().max()     # two bf16 layers of residual stream
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SP = 2 with shift parallelism, two processes on the one GPU (collectives over gloo, staged through the host)
+# ---------------------------------------------------------------------------------------------------------------
+def _sp_worker(rank, world, port, out_q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        H.install()
+        if world > 1:
+            H.load_plugin()
+        from vllm.config import ParallelConfig, set_current_vllm_config
+        from vllm.distributed import parallel_state as ps
+        from vllm.v1.worker.gpu_model_runner import GPUModelRunner
+        kw = dict(ulysses_sequence_parallel_size=world, enable_shift_parallel=True, shift_parallel_threshold=16) if world > 1 else {}
+        cfg = _vllm_config(parallel=ParallelConfig(**kw))
+        cfg.parallel_config.rank = rank
+        ps.reset_for_tests()
+        ps.init_world_group(rank)
+        set_current_vllm_config(cfg)
+        ps.initialize_model_parallel(1, 1)
+        r = GPUModelRunner(cfg, torch.device(DEV))
+        r.load_model()
+        r.initialize_kv_cache((200, torch.bfloat16))
+        streams = _requests(3, 64, seed=4)
+        sched = H.MiniScheduler(16, 400)
+        for rid, s in streams.items():
+            sched.add(rid, [int(x) for x in s[:64]])
+        steer = Steered(r, sched, streams)
+        hs, toks = [], []
+        for _ in range(6):
+            so = sched.schedule()
+            steer.plan(so)
+            toks.append(sched.update(r.execute_model(so)))
+            hs.append(steer.hidden.float().cpu().numpy())      # by value through the queue
+        calls = None
+        if world > 1:
+            from arcticinference_amd.vllm_plugin import step_context
+            calls = dict(step_context.calls)
+        out_q.put((world, rank, toks, hs, calls))
+    except BaseException:
+        import traceback
+        out_q.put((world, rank, "error", traceback.format_exc(), None))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sp2_shift_on_the_gpu_matches_single_process():
+    """Ulysses SP = 2 (HIP pack / unpack kernels, all-to-all) for the prefill step and the shift replica (TP = 2) for the
+    decode steps, both attending through the HIP kernel over one KV cache: hidden states equal the single-process run."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+
+    def launch(world):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        ps = [ctx.Process(target=_sp_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in ps:
+            p.start()
+        res = [q.get(timeout=300) for _ in range(world)]
+        for p in ps:
+            p.join(60)
+        for x in res:
+            assert x[2] != "error", x[3]
+        return res
+
+    (_, _, ref_toks, ref_hs, _), = launch(1)
+    for _, rank, toks, hs, calls in launch(2):
+        assert toks == ref_toks, rank
+        for a, b in zip(ref_hs, hs):
+            assert np.allclose(a, b, atol=3e-2, rtol=3e-2), (rank, np.abs(a - b).max())
+        # 5 decode steps x 2 layers on the HIP kernel in shift mode; the prefill (192 tokens) on vLLM's backend in SP mode
+        assert calls["verify"] == 10 and calls["fallback"] == 2, calls

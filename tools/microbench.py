@@ -61,6 +61,86 @@ def attn(B=64, ctx=4096, qlen=4, Hq=32, Hkv=8, D=128, bs=16, layers=4, split=Fal
     print(f"attn{' fp8kv' if kv8 else ''} B={B} ctx={ctx} qlen={qlen} Hq={Hq} Hkv={Hkv} D={D}: {us:8.1f} us  {gb / us * 1e6 / 1e3:6.2f} TB/s (incl. combine)")
 
 
+def attn_mix(n_short=59, n_long=5, q_short=1, q_long=33, ctx=4224, Hq=32, Hkv=8, D=128, bs=16, layers=4, kv8=False):
+    """The steady-state step of bench.py: most requests carry no draft (q_len 1), a few a long suffix draft — one call
+    through the host-partitioned path (pair kernel) against its parts."""
+    B = n_short + n_long
+    nblk = (ctx + bs - 1) // bs
+    nb = B * nblk
+    kvs = [torch.randn(2, nb, bs, Hkv, D, device=dev, dtype=torch.bfloat16) for _ in range(layers)]
+    kw = {}
+    if kv8:
+        kvs = []
+        for _ in range(layers):
+            raw = torch.randint(0, 256, (2, nb, bs, Hkv, D), dtype=torch.uint8, device=dev)
+            raw[(raw & 0x7f) == 0x7f] = 0x30
+            kvs.append(raw.view(torch.float8_e4m3fn))
+        sc = torch.full((1,), 0.02, dtype=torch.float32, device=dev)
+        kw = dict(k_scale=sc, v_scale=sc)
+    bt = torch.randperm(nb, device=dev).to(torch.int32).view(B, nblk)
+    ql = [q_short] * n_short + [q_long] * n_long
+    T = sum(ql)
+    q = torch.randn(T, Hq, D, device=dev, dtype=torch.bfloat16)
+    seq = torch.full((B,), ctx, dtype=torch.int32, device=dev)
+    qsl = torch.tensor(np.concatenate([[0], np.cumsum(ql)]).astype(np.int32), device=dev)
+    out = torch.empty_like(q)
+    rs = ops.split_requests(ql, Hq // Hkv, dev) if n_long else (torch.arange(B, dtype=torch.int32, device=dev), B, None, 0)
+    i = [0]
+
+    def f():
+        kv = kvs[i[0] % layers]
+        i[0] += 1
+        ops.verify_attention(q, kv[0], kv[1], bt, seq, qsl, max(ql), ctx, D ** -0.5, out=out, req_split=rs, **kw)
+    us = timeit(f)
+    gb = B * ctx * 2 * Hkv * D * (1 if kv8 else 2) / 1e9
+    print(f"attn-mix{' fp8kv' if kv8 else ''} short={n_short}x{q_short} long={n_long}x{q_long} ctx={ctx} Hq={Hq} Hkv={Hkv}: {us:8.1f} us  "
+          f"{gb / us * 1e6 / 1e3:6.2f} TB/s (incl. combine)")
+
+
+def attn_trace(n_short=59, n_long=5, q_short=1, q_long=33, ctx=4224, Hq=32, Hkv=8, D=128, bs=16):
+    """Where and when the workgroups of the one-grid short + long launch run (aic_debug_attn_trace)."""
+    B = n_short + n_long
+    nblk = (ctx + bs - 1) // bs
+    nb = B * nblk
+    kv = torch.randn(2, nb, bs, Hkv, D, device=dev, dtype=torch.bfloat16)
+    bt = torch.randperm(nb, device=dev).to(torch.int32).view(B, nblk)
+    ql = [q_short] * n_short + [q_long] * n_long
+    q = torch.randn(sum(ql), Hq, D, device=dev, dtype=torch.bfloat16)
+    seq = torch.full((B,), ctx, dtype=torch.int32, device=dev)
+    qsl = torch.tensor(np.concatenate([[0], np.cumsum(ql)]).astype(np.int32), device=dev)
+    out = torch.empty_like(q)
+    rs = ops.split_requests(ql, Hq // Hkv, dev)
+    run = lambda: ops.verify_attention(q, kv[0], kv[1], bt, seq, qsl, max(ql), ctx, D ** -0.5, out=out, req_split=rs)
+    for _ in range(3):
+        run()
+    buf = torch.full((2048, 4), -1, dtype=torch.int64, device=dev)
+    N.lib().aic_debug_attn_trace(buf.data_ptr(), 2048)
+    run()
+    torch.cuda.synchronize()
+    N.lib().aic_debug_attn_trace(None, 0)
+    t = buf.cpu().numpy()
+    t = t[t[:, 3] >= 0]
+    t0 = t[:, 0].min()
+    start, end = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0       # us
+    hw, xcc = t[:, 2] & 0xffffffff, t[:, 2] >> 32
+    cu = (xcc & 0xf) * 64 + ((hw >> 13) & 7) * 16 + ((hw >> 8) & 0xf)      # (xcc, se, cu) -> one id
+    print(f"trace short={n_short}x{q_short} long={n_long}x{q_long}: {len(t)} workgroups, kernel {end.max():.1f} us")
+    for kind, name in ((1, "long"), (0, "short")):
+        m = t[:, 3] == kind
+        if not m.any():
+            continue
+        print(f"  {name:5s}: n={m.sum():4d}  start min/med/max {start[m].min():7.1f} {np.median(start[m]):7.1f} {start[m].max():7.1f}   "
+              f"end min/med/max {end[m].min():7.1f} {np.median(end[m]):7.1f} {end[m].max():7.1f}   duration med {np.median(end[m] - start[m]):7.1f}   "
+              f"distinct CUs {len(set(cu[m]))}")
+    both = set(cu[t[:, 3] == 1]) & set(cu[t[:, 3] == 0])
+    per_cu = {}
+    for c, k in zip(cu, t[:, 3]):
+        per_cu.setdefault(int(c), []).append(int(k))
+    mix = sorted((tuple(sorted(v)) for v in per_cu.values()))
+    from collections import Counter
+    print(f"  CUs used {len(per_cu)}; CUs with both kinds {len(both)}; per-CU mix {Counter(mix).most_common(6)}")
+
+
 def lstm(B, fp8=True):
     from arcticinference_amd.speculator import ArcticLSTMSpeculator, LSTMSpeculatorConfig, random_lstm_weights
     cfg = LSTMSpeculatorConfig(vocab_size=128256, input_hidden_dim=4096)
@@ -108,6 +188,20 @@ if __name__ == "__main__":
         attn(B=16, qlen=17, split=True)
         attn(B=5, qlen=33, split=True)
         attn(B=1, qlen=33, split=True)
+    if "trace" in what:
+        attn_trace(59, 5)
+        attn_trace(56, 8)
+    if "mix" in what:
+        attn_mix(64, 0)
+        attn_mix(59, 5)
+        attn_mix(59, 0)
+        attn_mix(0, 5)
+        attn_mix(56, 8)
+        attn_mix(59, 5, q_long=17)
+        attn_mix(59, 5, q_short=4)
+        attn_mix(59, 5, kv8=True)
+        attn_mix(8, 1, Hq=4, Hkv=1)      # SP = 8 slice
+        attn_mix(59, 5, Hq=4, Hkv=1)
     if "lstm" in what:
         lstm(64)
         lstm(32)
