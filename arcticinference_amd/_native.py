@@ -89,6 +89,8 @@ _SIGNATURES = {
     "aic_reshape_and_cache_flash_bulk": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_void_p,
                                                  c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int,
                                                  c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
+    "aic_ulysses_pack_pair": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "aic_ulysses_reorder_split_kv": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_int32), c_void_p]),
     "aic_debug_attn_trace": (c_int, [c_void_p, c_int]),
     "aic_row_gather": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64),
                                POINTER(c_int32), c_void_p, c_int, c_int, c_void_p]),
@@ -101,6 +103,7 @@ _SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p]),
     "aic_lstm_create": (c_int, [POINTER(LstmConfig), POINTER(LstmWeights), POINTER(c_void_p)]),
     "aic_mlp_create": (c_int, [POINTER(LstmConfig), POINTER(MlpWeights), POINTER(c_void_p)]),
+    "aic_mlp_set_embedding_rows": (c_int, [c_void_p, c_void_p]),
     "aic_lstm_destroy": (None, [c_void_p]),
     "aic_quantize_fp8_per_tensor": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "aic_lstm_padding_size": (c_int, [c_int]),

@@ -456,7 +456,7 @@ __global__ void __launch_bounds__(1024)
 mlp_cell_kernel(const float* __restrict__ part, int n_splits, int m_pad, int batch, const int32_t* __restrict__ tokens,
                 const uint16_t* __restrict__ emb, int vocab_rows, float alpha, const uint16_t* __restrict__ ln_w,
                 const uint16_t* __restrict__ ln_b, int Ds, int MT, uint4* __restrict__ h_out,
-                unsigned int* __restrict__ amax_bits) {
+                unsigned int* __restrict__ amax_bits, int ext_rows) {
   extern __shared__ float smem[];  // [Ds]
   __shared__ float sh[16];
   const int m = blockIdx.x;
@@ -466,7 +466,8 @@ mlp_cell_kernel(const float* __restrict__ part, int n_splits, int m_pad, int bat
   }
   int tok = tokens[m];
   if (tok < 0 || tok >= vocab_rows) tok = 0;
-  const uint16_t* z = emb + static_cast<int64_t>(tok) * Ds;
+  // ext_rows: `emb` is [batch][Ds], the embedding rows already looked up (vocab-sharded table + all-reduce, C9)
+  const uint16_t* z = emb + static_cast<int64_t>(ext_rows ? m : tok) * Ds;
   float ss = 0.0f;
   for (int j = threadIdx.x; j < Ds; j += blockDim.x) {
     float s = 0.0f;
@@ -608,6 +609,7 @@ struct aic_lstm {
   uint4* mlp_head8_t[8] = {};
   float mlp_head8_scale[8] = {};
   const uint16_t* mlp_emb[8] = {};
+  const uint16_t* ext_rows = nullptr;   // [batch][Ds] embedding rows of the current head, looked up by the caller (C9)
   const uint16_t* mlp_ln_w[8] = {};
   const uint16_t* mlp_ln_b[8] = {};
   std::vector<void*> mlp_owned;
@@ -648,9 +650,11 @@ static int run_head(aic_lstm* m, int head_index, hipStream_t s, int64_t* out_tok
     rc = launch_gemm<false, 0>(mt, grid, s, m->mlp_proj_t[head_index], first ? m->x0 : m->h_bf16, rowtiles, steps_total,
                                steps_total / splits, m->part, Ds, nullptr, 1.0f, 0, 0, nullptr, nullptr);
     if (rc != AIC_OK) return rc;
+    const uint16_t* emb_src = m->ext_rows ? m->ext_rows : m->mlp_emb[head_index];
+    AIC_REQUIRE(emb_src, "head %d has no embedding table and no looked-up rows (aic_mlp_set_embedding_rows)", head_index);
     hipLaunchKernelGGL(mlp_cell_kernel, dim3(mpad), dim3(1024), Ds * sizeof(float), s, m->part, splits, mpad, B, m->tokens,
-                       m->mlp_emb[head_index], 0x7fffffff, m->alpha, m->mlp_ln_w[head_index], m->mlp_ln_b[head_index], Ds,
-                       mt, m->h_bf16, m->amax + head_index);
+                       emb_src, 0x7fffffff, m->alpha, m->mlp_ln_w[head_index], m->mlp_ln_b[head_index], Ds,
+                       mt, m->h_bf16, m->amax + head_index, m->ext_rows ? 1 : 0);
     if ((rc = launch_status("mlp_cell_kernel")) != AIC_OK) return rc;
     // 3. LM head + fused arg-max
     const bool fp8m = m->mlp_head8_t[head_index] && mpad <= c.head_fp8_max_batch;
@@ -821,7 +825,8 @@ int aic_mlp_create(const aic_lstm_config* cfg, const aic_mlp_weights* w, aic_lst
               "vocab_size / n_predict must be positive and max_batch in 1..64");
   AIC_REQUIRE(w->num_heads > 0 && w->num_heads <= 8, "an MLP speculator has 1..8 heads");
   for (int i = 0; i < w->num_heads; ++i)
-    AIC_REQUIRE(w->emb[i] && w->proj[i] && w->ln_w[i] && w->ln_b[i] && w->head[i], "missing weight pointer of head %d", i);
+    // emb[i] may be NULL: a vocab-sharded embedding is looked up by the caller (aic_mlp_set_embedding_rows)
+    AIC_REQUIRE(w->proj[i] && w->ln_w[i] && w->ln_b[i] && w->head[i], "missing weight pointer of head %d", i);
   AIC_NEED_DEVICE();
   aic_lstm* m = new aic_lstm();
   m->cfg = *cfg;
@@ -909,6 +914,12 @@ void aic_lstm_destroy(aic_lstm* m) {
   for (void* b : m->mlp_owned)
     if (b) (void)hipFree(b);
   delete m;
+}
+
+int aic_mlp_set_embedding_rows(aic_lstm* m, const void* rows) {
+  AIC_REQUIRE(m && m->mlp, "aic_mlp_set_embedding_rows needs an MLP speculator handle");
+  m->ext_rows = static_cast<const uint16_t*>(rows);
+  return AIC_OK;
 }
 
 int aic_lstm_begin(aic_lstm* m, const void* hidden, const int32_t* hidden_index, int batch, void* stream) {

@@ -38,3 +38,13 @@ def all_to_all_single(recv: torch.Tensor, send: torch.Tensor, group=None) -> Non
         recv.copy_(torch.cat(outs).view(recv.shape))
         return
     dist.all_to_all_single(recv, send, group=group)
+
+
+def all_reduce(t: torch.Tensor, group=None) -> None:
+    """Sum in place."""
+    if t.is_cuda and _staged(group):
+        host = t.cpu()
+        dist.all_reduce(host, group=group)
+        t.copy_(host)
+        return
+    dist.all_reduce(t, group=group)

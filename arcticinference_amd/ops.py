@@ -100,13 +100,21 @@ class RejectionResult:
 
 
 _ws_cache = {}
+_ws_retired = []     # outgrown workspaces stay alive: a kernel on a caller-supplied stream may still be reading one
 
 
-def _workspace(nbytes: int, device) -> torch.Tensor:
-    key = (device.index, "ws")
+def _workspace(nbytes: int, device, stream: Optional[int] = None, purpose: str = "attn") -> torch.Tensor:
+    """Scratch memory of one (device, stream, purpose): calls enqueued on different streams never share partials, and
+    attention (per-layer, possibly on a side stream) never shares with the acceptance kernel.  Sizes only grow (by
+    doubling), so the retired list stays a handful of blocks."""
+    if stream is None:
+        stream = N.current_stream_ptr()
+    key = (device.index, int(stream or 0), purpose)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        if ws is not None:
+            _ws_retired.append(ws)
+        ws = torch.empty(max(nbytes, 1 << 20, 0 if ws is None else 2 * ws.numel()), dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
     return ws
 
@@ -139,7 +147,8 @@ def rejection_sample(target_logits: torch.Tensor, draft_token_ids: torch.Tensor,
     nacc = torch.empty(B, dtype=torch.int32, device=dev)
     last = torch.empty(B, dtype=torch.int32, device=dev)
     hidx = torch.empty(B, dtype=torch.int32, device=dev)
-    ws = _workspace(N.lib().aic_rejection_workspace_bytes(rows + (B if bonus_row_index is not None else 0), V), dev)
+    ws = _workspace(N.lib().aic_rejection_workspace_bytes(rows + (B if bonus_row_index is not None else 0), V), dev,
+                    purpose="accept")
     draft = draft_token_ids.to(torch.int32)
     cu = cu_num_draft_tokens.to(torch.int32)
     bonus = None if bonus_token_ids is None else bonus_token_ids.reshape(-1).to(torch.int32)
@@ -183,7 +192,7 @@ def verify_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
         out = torch.empty((T, Hq, D), dtype=q.dtype, device=q.device)
     B = seq_lens.numel()
     wsb = N.lib().aic_verify_attention_workspace_bytes(T, Hq, D, num_splits_max)
-    ws = _workspace(wsb, q.device)
+    ws = _workspace(wsb, q.device, stream)
     kvd = N.torch_dtype_code(k_cache.dtype)
     if req_split is None and q_lens_host is not None:
         req_split = split_requests(q_lens_host, Hq // Hkv, q.device)
@@ -210,7 +219,7 @@ class VerifyAttentionPlan:
         T, Hq, D = q.shape
         nb, bs, Hkv, D2 = kv_like.shape
         assert D == D2 and q.stride(2) == 1 and q.stride(1) == D and out.shape == q.shape
-        ws = _workspace(N.lib().aic_verify_attention_workspace_bytes(T, Hq, D, num_splits_max), q.device)
+        ws = _workspace(N.lib().aic_verify_attention_workspace_bytes(T, Hq, D, num_splits_max), q.device, stream)
         short, n_short, long_, n_long = req_split if req_split is not None else (None, 0, None, 0)
         self._keep = (q, out, block_table, seq_lens, query_start_loc, ws, short, long_, k_scale, v_scale)
         self._fn = N.lib().aic_verify_attention_ex
@@ -292,6 +301,33 @@ def ulysses_unpack_out(recv: torch.Tensor, sp: int) -> torch.Tensor:
     out = torch.empty((n, sp * w), dtype=recv.dtype, device=recv.device)
     N.check(N.lib().aic_ulysses_unpack_out(recv.data_ptr(), out.data_ptr(), n, sp, w, N.current_stream_ptr()))
     return out
+
+
+def ulysses_pack_pair(a: torch.Tensor, b: Optional[torch.Tensor], parts: int) -> torch.Tensor:
+    """KV-replicated variant (ulysses.py:463-474): a [n, parts*aw] (and b [n, parts*bw]) -> send [parts*n, aw (+ bw)],
+    part-major: the q pack for the all-to-all over SP (b None) and the K|V pack for the all-to-all inside SP_AA."""
+    _need_cuda(a, b)
+    n = a.size(0)
+    aw = a.size(1) // parts
+    bw = 0 if b is None else b.size(1) // parts
+    send = torch.empty((parts * n, aw + bw), dtype=a.dtype, device=a.device)
+    N.check(N.lib().aic_ulysses_pack_pair(a.data_ptr(), _ptr(b), a.stride(0), 0 if b is None else b.stride(0),
+                                          send.data_ptr(), n, parts, aw, bw, N.current_stream_ptr()))
+    return send
+
+
+def ulysses_reorder_split_kv(gathered: torch.Tensor, sp: int, order: Sequence[int]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """gathered [sp*n, 2*kw] in all-gather chunk order -> (k, v) [sp*n, kw] each with chunk c taken from chunk order[c]
+    (ulysses.py:486-490: chunk / cat in `self.order` / split)."""
+    _need_cuda(gathered)
+    rows, w2 = gathered.shape
+    n, kw = rows // sp, w2 // 2
+    k = torch.empty((rows, kw), dtype=gathered.dtype, device=gathered.device)
+    v = torch.empty((rows, kw), dtype=gathered.dtype, device=gathered.device)
+    arr = (ctypes.c_int32 * sp)(*[int(x) for x in order])
+    N.check(N.lib().aic_ulysses_reorder_split_kv(gathered.data_ptr(), k.data_ptr(), v.data_ptr(), n, sp, kw, arr,
+                                                 N.current_stream_ptr()))
+    return k, v
 
 
 def quantize_fp8_per_tensor(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -260,7 +260,14 @@ class ArcticMLPSpeculator(ArcticLSTMSpeculator):
     LSTM speculator (generate_proposals, load_weights, the vocab-parallel begin / head_step / pick_global loop)."""
 
     def __init__(self, config: MLPSpeculatorConfig, max_num_seqs: int = 64, tp_size: int = 1, tp_rank: int = 0,
-                 tp_group=None, device: str = "cuda", quantize_lm_head: bool = True, use_graph: bool = False):
+                 tp_group=None, device: str = "cuda", quantize_lm_head: bool = True, use_graph: bool = False,
+                 shard_embedding: Optional[bool] = None, all_reduce=None):
+        # C9 (vocab_parallel_embedding.py:425-444): with tp_size > 1 the token embedding is sharded by vocabulary rows
+        # like the LM head (each rank keeps V / tp rows of every emb.{i}: 1 GB -> 128 MB per stage at V = 128256,
+        # Ds = 4096, tp = 8); a head looks its rows up on the local shard (zeros for tokens of other ranks) and
+        # all-reduces the [B, Ds] rows over the group.  `all_reduce(tensor)` is injectable (tests emulate the group).
+        self.shard_embedding = (tp_size > 1) if shard_embedding is None else bool(shard_embedding)
+        self._all_reduce = all_reduce
         self.config = config
         self.n_predict = config.n_predict
         self.vocab_size = config.vocab_size
@@ -306,19 +313,20 @@ class ArcticMLPSpeculator(ArcticLSTMSpeculator):
         cache: Dict[str, torch.Tensor] = {}
 
         def take(name: str, shape, local_rows: bool = False) -> torch.Tensor:
-            if name not in cache:
+            if (name, local_rows) not in cache:
                 if name not in w:
                     raise KeyError(f"speculator checkpoint is missing '{name}'")
                 t = w[name]
                 assert tuple(t.shape) == tuple(shape), (name, tuple(t.shape), tuple(shape))
                 if local_rows:
                     t = t[self.shard_start:self.shard_start + self.shard_rows]
-                cache[name] = bf(t)
-            return cache[name]
+                cache[(name, local_rows)] = bf(t)
+            return cache[(name, local_rows)]
 
         self.weights = {"emb": [], "proj": [], "ln_w": [], "ln_b": [], "head": []}
         for i in range(k):
-            self.weights["emb"].append(take(f"emb.{self._stage(i, 'emb')}.weight", (self.vocab_size, Ds)))
+            self.weights["emb"].append(take(f"emb.{self._stage(i, 'emb')}.weight", (self.vocab_size, Ds),
+                                            local_rows=self.shard_embedding))
             self.weights["proj"].append(take(f"proj.{self._stage(i, 'proj')}.weight", (Ds, H if i == 0 else Ds)))
             self.weights["ln_w"].append(take(f"ln.{self._stage(i, 'ln')}.weight", (Ds,)))
             self.weights["ln_b"].append(take(f"ln.{self._stage(i, 'ln')}.bias", (Ds,)))
@@ -337,7 +345,7 @@ class ArcticMLPSpeculator(ArcticLSTMSpeculator):
         wt = N.MlpWeights()
         wt.num_heads = k
         for i in range(k):
-            wt.emb[i] = W["emb"][i].data_ptr()
+            wt.emb[i] = None if self.shard_embedding else W["emb"][i].data_ptr()
             wt.proj[i] = W["proj"][i].data_ptr()
             wt.ln_w[i] = W["ln_w"][i].data_ptr()
             wt.ln_b[i] = W["ln_b"][i].data_ptr()
@@ -354,6 +362,49 @@ class ArcticMLPSpeculator(ArcticLSTMSpeculator):
             "out": torch.zeros(mb, self.max_speculative_tokens, dtype=torch.int64, device=self.device),
             "vals": torch.zeros(mb, self.max_speculative_tokens, dtype=torch.float32, device=self.device),
         }
+
+
+    # -- C9: sharded embedding ---------------------------------------------------------------------------------
+    def embedding_rows(self, head: int, last_tokens: torch.Tensor, batch: int) -> torch.Tensor:
+        """[batch, Ds] bf16: emb.{head}[token] assembled over the group — this rank contributes the rows of the tokens its
+        shard owns, zeros otherwise (get_masked_input_and_mask + masked_fill_, :161-178,:425-441), then the all-reduce."""
+        from .swiftkv import row_gather
+        if not hasattr(self, "_z"):
+            self._z = torch.empty(self.max_batch, self.inner_dim, dtype=torch.bfloat16, device=self.device)
+        z = self._z[:batch]
+        z.zero_()
+        local = last_tokens.to(torch.int64) - self.shard_start          # rows outside [0, shard_rows) are skipped
+        if self.shard_rows > 0:
+            row_gather([self.weights["emb"][head]], [z], local)
+        if self._all_reduce is not None:
+            self._all_reduce(z)
+        elif self.tp_size > 1:
+            from .dist_utils import all_reduce
+            all_reduce(z, group=self.tp_group)
+        return z
+
+    def head_step(self, head: int, last_tokens: torch.Tensor, batch: int):
+        if self.shard_embedding:
+            z = self.embedding_rows(head, last_tokens, batch)
+            N.check(N.lib().aic_mlp_set_embedding_rows(self._h, z.data_ptr()))
+        return super().head_step(head, last_tokens, batch)
+
+    def generate_proposals(self, input_ids, previous_hidden_states, num_predict_tokens, hidden_index=None):
+        if self.shard_embedding and self.tp_size == 1:
+            # a sharded table on one rank (tests): the head loop with the lookup in front of every head
+            if num_predict_tokens > self.max_speculative_tokens:
+                raise ValueError(f"Max speculative tokens for model is {self.max_speculative_tokens}, but "
+                                 f"{num_predict_tokens} were requested")
+            B = input_ids.size(0)
+            hs = previous_hidden_states.to(torch.bfloat16).contiguous()
+            self.begin(hs, None if hidden_index is None else hidden_index.to(torch.int32), B)
+            last, outs = input_ids.to(torch.int32), []
+            for head in range(num_predict_tokens):
+                tok, _ = self.head_step(head, last, B)
+                outs.append(tok.unsqueeze(1))
+                last = tok.to(torch.int32)
+            return torch.cat(outs, dim=-1)
+        return super().generate_proposals(input_ids, previous_hidden_states, num_predict_tokens, hidden_index)
 
 
 def random_mlp_weights(cfg: MLPSpeculatorConfig, seed: int = 0, std: float = 0.02

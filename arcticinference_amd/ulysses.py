@@ -143,8 +143,19 @@ def _hip_unpack(c, sp):
     return ops.ulysses_unpack_out(c, sp)
 
 
+def _hip_pack_pair(a, b, parts):
+    from . import ops
+    return ops.ulysses_pack_pair(a, b, parts)
+
+
+def _hip_reorder_split(gathered, sp, order):
+    from . import ops
+    return ops.ulysses_reorder_split_kv(gathered, sp, order)
+
+
 # the copy kernels a UlyssesAttention uses unless told otherwise; CPU (gloo) tests put torch expressions here
-PACK_FNS = [_hip_pack, _hip_unpack]
+# (pack q|k|v, unpack out; KV-replicated variant: pack one or two tensors part-major, reorder + split the gathered K|V)
+PACK_FNS = [_hip_pack, _hip_unpack, _hip_pack_pair, _hip_reorder_split]
 
 
 class UlyssesAttention:
@@ -158,7 +169,7 @@ class UlyssesAttention:
     head.  q takes the usual all-to-all over SP; K/V take an all-to-all inside the rank's SP_AA group (size = number of
     kv heads: shards the heads) followed by an all-gather inside its SP_AG group (size SP / kv heads: collects the
     tokens), and the gathered token chunks are put back into rank order.  Pass `kv_groups=(aa_group, aa_size,
-    ag_group, ag_size)`; the copies of this variant are torch expressions (decode-size tensors)."""
+    ag_group, ag_size)`; its copies are HIP kernels as well (pack_pair / reorder_split_kv, csrc/ulysses_pack.hip)."""
 
     def __init__(self, sp_size: int, group, num_q_heads_local: int, num_kv_heads_local: int, head_size: int,
                  pack: Optional[Callable] = None, unpack: Optional[Callable] = None, all_to_all: Optional[Callable] = None,
@@ -193,12 +204,13 @@ class UlyssesAttention:
         if self.kv_groups is not None:
             aa_group, aa, ag_group, ag = self.kv_groups
             sp = self.sp_size
+            pack_pair, reorder_split = PACK_FNS[2], PACK_FNS[3]
             # q: all-to-all 1/2 over SP (ulysses.py:463-469)
-            q = query.view(-1, sp, qw).transpose(0, 1).reshape(-1, qw)
+            q = pack_pair(query, None, sp)
             q_ = torch.empty_like(q)
             self._all_to_all(q_, q, self.group)
             # K/V: heads sharded inside SP_AA, tokens collected inside SP_AG, chunks back in rank order (:470-490)
-            kv = torch.cat((key.view(-1, aa, kw), value.view(-1, aa, kw)), dim=-1).transpose(0, 1).reshape(-1, 2 * kw)
+            kv = pack_pair(key, value, aa)
             kv_part = torch.empty_like(kv)
             self._all_to_all(kv_part, kv, aa_group)
             kv_ = torch.empty(q_.shape[0], 2 * kw, dtype=query.dtype, device=query.device)
@@ -207,9 +219,7 @@ class UlyssesAttention:
             else:
                 from .dist_utils import all_gather_into_tensor
                 all_gather_into_tensor(kv_, kv_part, group=ag_group)
-            chunks = kv_.chunk(sp)
-            kv_ordered = torch.cat([chunks[i] for i in self.order])
-            k_, v_ = kv_ordered.split([kw, kw], dim=-1)
+            k_, v_ = reorder_split(kv_, sp, self.order)
             c_ = attn(q_, k_, v_)
         else:
             send = self.pack(query, key, value, self.sp_size)               # [SP*n, qw + 2kw], rank-major

@@ -270,6 +270,11 @@ typedef struct aic_mlp_weights {
   const void* head[8];      /* bf16 [V_local, Ds] */
 } aic_mlp_weights;
 int aic_mlp_create(const aic_lstm_config* cfg, const aic_mlp_weights* w, aic_lstm** out);
+/* C9 (vocab_parallel_embedding.py:425-444): with the token embedding sharded over the speculator's TP group the caller
+ * looks the rows up on its shard (zeros for tokens it does not own), all-reduces them, and hands the [batch][inner_dim]
+ * bf16 rows to the next aic_lstm_head call of an MLP speculator; NULL goes back to the handle's own tables (which
+ * aic_mlp_create accepts as NULL pointers when only looked-up rows will be used). */
+int aic_mlp_set_embedding_rows(aic_lstm* m, const void* rows /*device, or NULL*/);
 void aic_lstm_destroy(aic_lstm* m);
 /* per-tensor e4m3fn quantisation of a bf16 matrix: scale = amax/448, q = sat(x/scale)
  * (ops.scaled_fp8_quant with scale=None, fp8.py:207-210).  scale_out: device f32[1]. */
@@ -342,6 +347,17 @@ int aic_ulysses_pack_qkv(const void* q, const void* k, const void* v, int64_t q_
 int aic_ulysses_split_qkv(const void* recv, void* q, void* k, void* v, int64_t rows, int q_width, int kv_width,
                           void* stream);
 int aic_ulysses_unpack_out(const void* recv, void* out, int n_local, int sp, int width, void* stream);
+
+/* KV-replicated variant, fewer kv heads than SP ranks (ulysses.py:462-490): q is packed alone for the all-to-all over
+ * SP, K|V are packed for the all-to-all inside the rank's SP_AA group (`parts` = kv heads), and the all-gathered
+ * K|V chunks (SP_AG-major) are put back into rank order and split:
+ *   pack_pair   : a [n][parts*aw], b [n][parts*bw]  ->  send [parts][n][aw + bw]      (b NULL / bw 0: a alone)
+ *   reorder     : gathered [sp][n][2*kw]  ->  k [sp*n][kw], v [sp*n][kw] with destination chunk c = source chunk order[c]
+ * `order` is a HOST array of sp ints (a permutation: [j * aa + i for i in range(aa) for j in range(ag)], :449-451). */
+int aic_ulysses_pack_pair(const void* a, const void* b, int64_t a_stride, int64_t b_stride, void* send, int n_local,
+                          int parts, int a_width, int b_width, void* stream);
+int aic_ulysses_reorder_split_kv(const void* gathered, void* k, void* v, int n_chunk_rows, int sp, int kv_width,
+                                 const int32_t* order /*host*/, void* stream);
 
 #ifdef __cplusplus
 }

@@ -56,8 +56,10 @@ def fp8_quant_per_tensor(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
 
 def lstm_generate_proposals(w: Dict[str, torch.Tensor], input_ids: torch.Tensor, hidden: torch.Tensor, k: int,
                             n_predict: int, scale_input: bool = True, fp8_head: bool = False,
-                            return_logits: bool = False):
-    """generate_states + generate_token_ids for method == "sum_lstm", tp_size == 1
+                            return_logits: bool = False, forced_tokens: torch.Tensor = None):
+    """`forced_tokens` [B, k]: feed THESE tokens to the next head instead of the oracle's own arg-max (teacher forcing:
+    lets a test judge every head of a row after the kernel and the oracle parted at a near-tie).
+    generate_states + generate_token_ids for method == "sum_lstm", tp_size == 1
     (arctic_speculator.py:648-751), on CPU bf16.  `w` uses the module's parameter names after the
     reference loader ran: projs.{0,1}.weight = cat(forget, input, output, cell) (:886-891)."""
     dt = torch.bfloat16
@@ -98,13 +100,15 @@ def lstm_generate_proposals(w: Dict[str, torch.Tensor], input_ids: torch.Tensor,
         last = torch.argmax(logits, dim=-1).reshape(-1, 1)
         out.append(last)
         all_logits.append(logits)
+        if forced_tokens is not None:
+            last = forced_tokens[:, head_index].long().reshape(-1, 1)
     toks = torch.cat(out, dim=-1)
     return (toks, all_logits) if return_logits else toks
 
 
 def mlp_generate_proposals(w: Dict[str, torch.Tensor], input_ids: torch.Tensor, hidden: torch.Tensor, k: int,
                            n_predict: int, inner_dim: int, tie_weights: bool, scale_input: bool = False,
-                           fp8_head: bool = False, return_logits: bool = False):
+                           fp8_head: bool = False, return_logits: bool = False, forced_tokens: torch.Tensor = None):
     """ArcticMLPSpeculator.generate_states + generate_token_ids, tp_size == 1 (arctic_speculator.py:264-321), on CPU
     bf16 with the module's parameter names (emb.i / proj.i / ln.i / head.i; tied models keep stage 0, proj 0 and 1)."""
     dt = torch.bfloat16
@@ -134,6 +138,8 @@ def mlp_generate_proposals(w: Dict[str, torch.Tensor], input_ids: torch.Tensor, 
         last = torch.argmax(logits, dim=-1).reshape(-1, 1)
         out.append(last)
         all_logits.append(logits)
+        if forced_tokens is not None:
+            last = forced_tokens[:, i].long().reshape(-1, 1)
     toks = torch.cat(out, dim=-1)
     return (toks, all_logits) if return_logits else toks
 
@@ -291,6 +297,23 @@ def ulysses_pack(q, k, v, sp, hq, hkv, D):
 
 def ulysses_unpack(c, sp, hq, D):
     return c.view(sp, -1, hq * D).transpose(0, 1).reshape(-1, hq * sp * D)
+
+
+def ulysses_pack_pair(a, b, parts):
+    """KV-replicated variant: the q pack (b None, ulysses.py:464-467) and the K|V pack (:471-474), part-major."""
+    n = a.shape[0]
+    if b is None:
+        return a.view(n, parts, -1).transpose(0, 1).reshape(parts * n, -1)
+    return torch.cat((a.view(n, parts, -1), b.view(n, parts, -1)), dim=-1).transpose(0, 1).reshape(parts * n, -1)
+
+
+def ulysses_reorder_split(gathered, sp, order):
+    """ulysses.py:486-490: chunk the all-gathered K|V, concatenate the chunks in `order`, split K from V."""
+    chunks = gathered.chunk(sp)
+    ordered = torch.cat([chunks[i] for i in order])
+    kw = gathered.shape[1] // 2
+    k, v = ordered.split([kw, kw], dim=-1)
+    return k.contiguous(), v.contiguous()
 
 
 def all_to_all_single_emulated(per_rank_inputs: List[torch.Tensor]) -> List[torch.Tensor]:

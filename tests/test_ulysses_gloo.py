@@ -134,6 +134,8 @@ def _worker_kv_replicated(rank, world, port, Hq, Hkv, D, N, out_q):
             s = s.masked_fill(~torch.tril(torch.ones(N, N, dtype=torch.bool)), float("-inf"))
             return (torch.softmax(s, -1) @ V).transpose(0, 1).reshape(N, hq * D).contiguous()
 
+        import arcticinference_amd.ulysses as U
+        U.PACK_FNS[2], U.PACK_FNS[3] = O.ulysses_pack_pair, O.ulysses_reorder_split    # (no GPU here: the literal expressions)
         ua = UlyssesAttention(world, dist.group.WORLD, hq, 1, D, unpack=lambda c, sp: O.ulysses_unpack(c, sp, hq, D),
                               kv_groups=(aa_group, aa, ag_group, ag))
         out = ua.forward(q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(), attn)

@@ -94,6 +94,7 @@ def _worker_body(rank, world, hkv, threshold, n_steps, out_q):
         # the HIP copy kernels cannot run here: the literal torch expressions of ulysses.py:493-517 stand in
         U.PACK_FNS[0] = lambda q, k, v, sp: O.ulysses_pack(q, k, v, sp, q.shape[1] // sp // 64, k.shape[1] // sp // 64, 64)
         U.PACK_FNS[1] = lambda c, sp: O.ulysses_unpack(c, sp, c.shape[1] // 64, 64)
+        U.PACK_FNS[2], U.PACK_FNS[3] = O.ulysses_pack_pair, O.ulysses_reorder_split
         from vllm.config import set_current_vllm_config
         from vllm.distributed import parallel_state as ps
         from vllm.forward_context import history
