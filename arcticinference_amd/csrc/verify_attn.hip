@@ -1111,7 +1111,9 @@ static int cu_count() {
 // `wgs_per_cu`: how many workgroups of the body should share a CU.  The short body streams: one per CU measured best.
 // The shared-tile (long-draft) body is bound by its own MFMA + VALU chain per tile and wants a second workgroup on the
 // CU to fill its stalls (alone, one wave per SIMD, it ran at 2 us per 32-token tile).
-static int pick_splits(int n_items, int max_seq_len, int min_tiles_per_split, int wgs_per_cu = 1) {
+// `max_wgs` > 0: never more workgroups than that (the one-grid short + long launch keeps the short part to one
+// workgroup per CU so that the long part has a resident slot on every CU).
+static int pick_splits(int n_items, int max_seq_len, int min_tiles_per_split, int wgs_per_cu = 1, int max_wgs = 0) {
   const int kCUs = cu_count() * wgs_per_cu;
   const int max_tiles = (max_seq_len + kTile - 1) / kTile;
   int cap = std::max(1, max_tiles / std::max(1, min_tiles_per_split));
@@ -1119,6 +1121,7 @@ static int pick_splits(int n_items, int max_seq_len, int min_tiles_per_split, in
   int best = 1;
   double best_cost = 1e30;
   for (int s = 1; s <= cap; ++s) {
+    if (s > 1 && max_wgs > 0 && static_cast<int64_t>(n_items) * s > max_wgs) break;
     const double wgs = static_cast<double>(n_items) * s;
     const double rounds = std::ceil(wgs / kCUs);
     // time ~ rounds * (work per workgroup) = rounds / s; normalised by the ideal n_items / kCUs
@@ -1247,7 +1250,12 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   const int hgroups = wave_heads ? num_kv_heads / 4 : num_kv_heads;
   const size_t rows = static_cast<size_t>(num_tokens) * num_q_heads;
   // splits of the short / generic launch and of the long-draft launch (its items are few: more splits)
-  int n_splits = pick_splits((split_lists ? std::max(n_short, 1) : batch) * hgroups, max_seq_len, wave_heads ? 2 : 8);
+  // with long drafts in the call the short part stays within one workgroup per CU (see pick_splits): measured with
+  // rocprofv3 on the bench, 50 short requests otherwise took 5 splits = 500 workgroups, left no room for the long part,
+  // and the call fell back to two launches whose long kernel alone ran 212 us
+  const bool mixed = split_lists && n_short > 0 && n_long > 0;
+  int n_splits = pick_splits((split_lists ? std::max(n_short, 1) : batch) * hgroups, max_seq_len, wave_heads ? 2 : 8, 1,
+                             mixed ? cu_count() : 0);
   int n_splits_long = (split_lists && n_long > 0) ? pick_splits(n_long * num_kv_heads, max_seq_len, 8, 2) : 0;
   auto fits = [&](int parts) { return static_cast<size_t>(parts) * rows * (kD + 2) * sizeof(float) <= workspace_bytes; };
   while (n_splits > 1 && !fits(n_splits)) --n_splits;

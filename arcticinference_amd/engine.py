@@ -240,6 +240,32 @@ class HotPathEngine:
         ctx = np.fromiter((len(r.tokens) for r in reqs), dtype=np.int32, count=B) + n_draft
         max_q, max_ctx = int(q_len.max()), int(ctx.max())
 
+        # Two staging copies per step.  (A) what the KV write and the attention launches need — contexts, query offsets,
+        # slots, the short / long request lists — goes first, and the 2 x L launches are enqueued right behind it.  (B) what
+        # only the acceptance needs — draft ids, the synthetic target's tokens, target / bonus row indices — is built
+        # while the GPU is already attending (rocprofv3 timeline of the r02 bench: 0.58 ms of GPU idle sat between the
+        # suffix kernels of one step and the staging copy of the next; building B first was a third of it).
+        slot_map = self._slot_mapping(live, reqs, q_len, qsl, T)
+        G = self.hq_local // self.hkv_local
+        so = ops.split_order(q_len, G)            # short / long request lists of the attention call
+        order = so[0] if so is not None else np.zeros(0, np.int32)
+        stA = self._stage("A", [(ctx, np.int32), (qsl, np.int32), (np.asarray(live), np.int64), (slot_map, np.int64),
+                                (order, np.int32)])
+        d_seq, d_qsl, slots, d_slots, order_dev = stA
+        bt = self.block_table.index_select(0, slots) if B != self.max_num_seqs else self.block_table
+
+        # (a) KV of the step's tokens for every layer in one launch (A16), then (b) verify attention per layer
+        self._write_kv(d_slots, T)
+        _mark('host_prepare')
+        self._req_split = None
+        if so is not None:
+            self._req_split = (order_dev[:so[1]], so[1], order_dev[so[1]:], len(so[0]) - so[1])
+        self._stream = int(torch.cuda.current_stream().cuda_stream)   # looked up once per step, not once per layer
+        self._attention_layers(T, bt, d_seq, d_qsl, max_q, max_ctx)
+        self.last_ctx_sum = int(ctx.sum())
+        _mark('enqueue_attention')
+
+        # ---- staging B (the GPU is busy with the attention launches from here on) ----
         # planted verify logits: row (request i, position p) gets the target's token for that position
         ql = q_len.tolist()
         plant_tok = np.concatenate([next_truth(r, ql[i]) for i, r in enumerate(reqs)]).astype(np.int64, copy=False)
@@ -265,50 +291,13 @@ class HotPathEngine:
         is_bonus[qsl[1:] - 1] = True
         target_rows = np.nonzero(~is_bonus)[0]
         bonus_rows = qsl[1:] - 1
-
-        # one pinned staging buffer and ONE host->device copy for all of the step's small index arrays
-        slot_map = self._slot_mapping(live, reqs, q_len, qsl, T)
-        G = self.hq_local // self.hkv_local
-        so = ops.split_order(q_len, G)            # short / long request lists of the attention call
-        parts = [ctx, qsl, draft_flat, cu_draft, plant_tok, target_rows, bonus_rows, np.asarray(live), slot_map,
-                 so[0] if so is not None else np.zeros(0, np.int32), fill_pos, fill_src]
-        kinds = [np.int32, np.int32, np.int32, np.int32, np.int64, np.int64, np.int64, np.int64, np.int64, np.int32,
-                 np.int64, np.int64]
-        offs, nbytes = [], 0
-        for a, k in zip(parts, kinds):
-            nbytes = (nbytes + 15) & ~15
-            offs.append(nbytes)
-            nbytes += len(a) * np.dtype(k).itemsize
-        if not hasattr(self, "_stage_pin") or self._stage_pin.numel() < nbytes:
-            self._stage_pin = torch.empty(max(nbytes * 2, 1 << 16), dtype=torch.uint8).pin_memory()
-            self._stage_dev = torch.empty(self._stage_pin.numel(), dtype=torch.uint8, device=dev)
-        host = self._stage_pin.numpy()
-        for a, k, o in zip(parts, kinds, offs):
-            host[o:o + len(a) * np.dtype(k).itemsize].view(k)[:] = a
-        self._stage_dev[:nbytes].copy_(self._stage_pin[:nbytes], non_blocking=True)
-
-        def dview(i, tdt):
-            k = np.dtype(kinds[i]).itemsize
-            return self._stage_dev[offs[i]:offs[i] + len(parts[i]) * k].view(tdt)
-        d_seq, d_qsl, d_draft, d_cu = (dview(i, torch.int32) for i in range(4))
-        d_plant, d_trows, d_brows, slots, d_slots = (dview(i, torch.int64) for i in range(4, 9))
-        bt = self.block_table.index_select(0, slots) if B != self.max_num_seqs else self.block_table
-
-        # (a) KV of the step's tokens for every layer in one launch (A16), then (b) verify attention per layer
-        self._write_kv(d_slots, T)
-        _mark('host_prepare')
-        self._req_split = None
-        if so is not None:
-            order_dev = dview(9, torch.int32)
-            self._req_split = (order_dev[:so[1]], so[1], order_dev[so[1]:], len(so[0]) - so[1])
-        self._stream = int(torch.cuda.current_stream().cuda_stream)   # looked up once per step, not once per layer
-        self._attention_layers(T, bt, d_seq, d_qsl, max_q, max_ctx)
-
-        # the LSTM draft ids of the previous step (still on the device) go into this step's draft array; only the
-        # acceptance below reads it, so the fill is enqueued behind the attention launches, off the critical path
+        d_draft, d_cu, d_plant, d_trows, d_brows, d_fpos, d_fsrc = self._stage(
+            "B", [(draft_flat, np.int32), (cu_draft, np.int32), (plant_tok, np.int64), (target_rows, np.int64),
+                  (bonus_rows, np.int64), (fill_pos, np.int64), (fill_src, np.int64)])
+        # the LSTM draft ids of the previous step (still on the device) go into this step's draft array
         if len(fill_pos):
-            d_draft.index_copy_(0, dview(10, torch.int64), prev_lstm.reshape(-1).index_select(0, dview(11, torch.int64)).to(torch.int32))
-        _mark('enqueue_attention')
+            d_draft.index_copy_(0, d_fpos, prev_lstm.reshape(-1).index_select(0, d_fsrc).to(torch.int32))
+        _mark('stage_acceptance')
         # (c) verify logits: plant, accept, un-plant
         lg = self.logits[:T]
         col = d_plant.unsqueeze(1)
@@ -434,6 +423,27 @@ class HotPathEngine:
         return emitted
 
     # -- pieces -------------------------------------------------------------------------------------------
+    _TORCH_OF = {np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64}
+
+    def _stage(self, which: str, arrays):
+        """One pinned buffer + ONE host->device copy for a group of small index arrays; returns their device views."""
+        bufs = self.__dict__.setdefault("_stage_bufs", {})
+        offs, nbytes = [], 0
+        for a, k in arrays:
+            nbytes = (nbytes + 15) & ~15
+            offs.append(nbytes)
+            nbytes += len(a) * np.dtype(k).itemsize
+        pin, dev = bufs.get(which, (None, None))
+        if pin is None or pin.numel() < nbytes:
+            pin = torch.empty(max(nbytes * 2, 1 << 16), dtype=torch.uint8).pin_memory()
+            dev = torch.empty(pin.numel(), dtype=torch.uint8, device=self.device)
+            bufs[which] = (pin, dev)
+        host = pin.numpy()
+        for (a, k), o in zip(arrays, offs):
+            host[o:o + len(a) * np.dtype(k).itemsize].view(k)[:] = a
+        dev[:nbytes].copy_(pin[:nbytes], non_blocking=True)
+        return [dev[o:o + len(a) * np.dtype(k).itemsize].view(self._TORCH_OF[np.dtype(k)]) for (a, k), o in zip(arrays, offs)]
+
     def _propose_suffix(self, live_arr, reqs, n_emit):
         """propose_suffix_draft_token_ids (model_runner.py:680-744) for the whole batch at once, on arrays.
         Returns (tokens [B, cap], n_tokens [B], score [B]); requests that are skipped keep n_tokens = 0."""

@@ -229,6 +229,10 @@ def build_ulysses_patches():
             another cache layout, no metadata): the caller then uses vLLM's backend."""
             if not query.is_cuda:
                 return None
+            if torch.cuda.is_current_stream_capturing():
+                # full-graph capture would freeze this step's host-side geometry (split counts, max_seq_len) into the
+                # graph; vLLM's default piecewise graphs run attention outside the captured pieces and never get here
+                return None
             ctx = get_forward_context()
             meta = ctx.attn_metadata
             if isinstance(meta, dict):

@@ -318,9 +318,8 @@ def main():
         # short-request body and the long-draft body are workgroups of the same grid):
         # sum_i ctx_i * 2 (K,V) * Hkv_local * D * bytes per element
         kvb = 2 if args.kv_dtype == "auto" else 1
-        ctx_all = sum(len(r.tokens) + r.num_drafts for r in eng.requests if r is not None)
-        attn_bytes[0] += ctx_all * 2 * eng.hkv_local * shape.head_size * kvb * shape.num_layers
         run_step()
+        attn_bytes[0] += eng.last_ctx_sum * 2 * eng.hkv_local * shape.head_size * kvb * shape.num_layers
     barrier()
     elapsed = time.perf_counter() - t0
     import ctypes
