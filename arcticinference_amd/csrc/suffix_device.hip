@@ -106,9 +106,10 @@ suffix_match_kernel(const QueryRec* __restrict__ queries, const TreeDesc* __rest
         const int4 a = *reinterpret_cast<const int4*>(&T.nodes[node]);                // count,parent,seq_slot,start
         const int4 b = *(reinterpret_cast<const int4*>(&T.nodes[node]) + 1);          // length,best,alive,pad
         node_count = uni(a.x);
-        node_len = uni(b.x);
         node_best = uni(b.y);
-        label = static_cast<int64_t>(uni(T.seq_base[uni(a.z)])) + uni(a.w);
+        const int2 sm = *reinterpret_cast<const int2*>(&T.seq_base[2 * uni(a.z)]);   // {region base, sequence length}
+        node_len = uni(b.x) != kOpenLength ? uni(b.x) : uni(sm.y) - uni(a.w);         // open leaf: to the sequence's end
+        label = static_cast<int64_t>(uni(sm.x)) + uni(a.w);
         idx = 0;
       }
       // compare the rest of this edge with the pattern, 64 tokens per step across the lanes
@@ -152,9 +153,10 @@ suffix_match_kernel(const QueryRec* __restrict__ queries, const TreeDesc* __rest
           const int4 a = *reinterpret_cast<const int4*>(&T.nodes[node]);
           const int4 b = *(reinterpret_cast<const int4*>(&T.nodes[node]) + 1);
           node_count = uni(a.x);
-          node_len = uni(b.x);
           node_best = uni(b.y);
-          label = static_cast<int64_t>(uni(T.seq_base[uni(a.z)])) + uni(a.w);
+          const int2 sm = *reinterpret_cast<const int2*>(&T.seq_base[2 * uni(a.z)]);
+          node_len = uni(b.x) != kOpenLength ? uni(b.x) : uni(sm.y) - uni(a.w);
+          label = static_cast<int64_t>(uni(sm.x)) + uni(a.w);
           idx = 0;
           prob = __fmul_rn(prob, __fdiv_rn(static_cast<float>(node_count), static_cast<float>(parent_count)));
         }
@@ -447,13 +449,27 @@ class Mirror {
         s.synced = have;
       }
     }
-    // seq_base table
-    if ((rc = grow(pool, &I.seq_base, &I.seq_cap, std::max<size_t>(seqs.size(), 1), &moved)) != AIC_OK) return rc;
+    // sequence table: {region base, current length} per sequence slot (open leaves read the length)
+    if ((rc = grow(pool, &I.seq_base, &I.seq_cap, 2 * std::max<size_t>(seqs.size(), 1), &moved)) != AIC_OK) return rc;
     if (moved || full || any_moved || I.seq_synced != seqs.size()) {
-      if ((rc = reserve(std::max<size_t>(seqs.size(), 1), &off)) != AIC_OK) return rc;
-      for (size_t k = 0; k < seqs.size(); ++k) at(off)[k] = seqs[k].base;
-      add_job(I.seq_base, off, -1, 0, static_cast<int32_t>(seqs.size()), 1);
+      if ((rc = reserve(2 * std::max<size_t>(seqs.size(), 1), &off)) != AIC_OK) return rc;
+      for (size_t k = 0; k < seqs.size(); ++k) {
+        at(off)[2 * k] = seqs[k].base;
+        at(off)[2 * k + 1] = static_cast<int32_t>(seqs[k].toks.size());
+      }
+      add_job(I.seq_base, off, -1, 0, static_cast<int32_t>(seqs.size()), 2);
       I.seq_synced = seqs.size();
+    } else if (!H.dirty_seqs().empty()) {
+      const size_t d = H.dirty_seqs().size();
+      if ((rc = reserve(d * 2, &off)) != AIC_OK) return rc;
+      if ((rc = reserve(d, &ioff)) != AIC_OK) return rc;
+      for (size_t k = 0; k < d; ++k) {
+        const int32_t si = H.dirty_seqs()[k];
+        at(off)[2 * k] = seqs[si].base;
+        at(off)[2 * k + 1] = static_cast<int32_t>(seqs[si].toks.size());
+        at(ioff)[k] = si;
+      }
+      add_job(I.seq_base, off, ioff, 0, static_cast<int32_t>(d), 2);
     }
     H.clear_dirty();
 
@@ -731,7 +747,12 @@ int aic_st_export(aic_suffix_tree* t, int32_t* n_nodes, int32_t* n_slots, int32_
   *n_slots = static_cast<int32_t>(H.slots().size());
   *n_tokens = H.pool_end();
   *n_seq_slots = static_cast<int32_t>(H.seqs().size());
-  if (nodes) std::memcpy(nodes, H.recs().data(), H.recs().size() * sizeof(NodeRec));
+  if (nodes) {
+    std::memcpy(nodes, H.recs().data(), H.recs().size() * sizeof(NodeRec));
+    // the exported image carries concrete edge lengths (open leaves resolved against their sequence's length)
+    for (size_t i = 0; i < H.recs().size(); ++i)
+      if (H.recs()[i].alive && H.recs()[i].length == kOpenLength) nodes[i * 8 + 4] = H.len_of(static_cast<int32_t>(i));
+  }
   if (hash) std::memcpy(hash, H.slots().data(), H.slots().size() * sizeof(HashSlot));
   if (tokens) {
     std::memset(tokens, 0xff, static_cast<size_t>(H.pool_end()) * 4);

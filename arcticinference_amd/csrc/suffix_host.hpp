@@ -10,7 +10,18 @@
 //     (suffix_tree.cc:208-214).  We keep one std::unordered_map<int,int32_t> per *internal* node,
 //     driven through the same insert / overwrite / erase sequence so its iteration order is the
 //     reference's by construction, and we resolve the scan at update time into NodeRec::best, so
-//     the device never iterates children: one dependent load per speculated hop.
+//     the device never iterates children: one dependent load per speculated hop;
+//   * OPEN LEAVES.  In the reference every appended token lengthens the private leaf of each of the
+//     <= max_depth active suffixes by one (suffix_tree.cc: `node->length += 1` for count == 1 nodes) —
+//     ~60 node writes per token, and here as many dirty records to mirror.  A private leaf's edge
+//     always runs to the END of its sequence while its suffix is active, so such a leaf stores
+//     length = kOpenLength and its length is read as seq_len(seq_slot) - start (Ukkonen's open
+//     leaves): appending a token costs it nothing.  It is given its concrete length ("closed") when
+//     its suffix leaves the active window, and before any structural operation reads its length —
+//     every such reader is an active suffix processed AFTER the leaf's owner in the same append (a
+//     node's children are deeper than the node, so only a shorter suffix can walk into a longer
+//     one's leaf), which is exactly when the reference has already lengthened it.  What remains per
+//     token: the root count, one closing, and the handful of structural updates.
 #pragma once
 
 #include <cstdint>
@@ -31,6 +42,8 @@ struct HostCandidate {
   float score = 0.0f;
   int32_t match_len = 0;
 };
+
+constexpr int32_t kOpenLength = -1;  // NodeRec::length of an open leaf (also read by the matcher kernels)
 
 class HostTree {
  public:
@@ -70,8 +83,12 @@ class HostTree {
       s0.active.push_back(0);
       recs_[0].count += 1;
       mark_node(0);
-      if (s0.active.size() > static_cast<size_t>(max_depth_)) s0.active.pop_front();
+      if (s0.active.size() > static_cast<size_t>(max_depth_)) {
+        close_leaf(s0.active.front());  // its suffix stops growing here: the edge ends at the sequence's current end
+        s0.active.pop_front();
+      }
       s0.toks.push_back(token);
+      mark_seq(slot);
     }
     const int32_t n_tok = static_cast<int32_t>(seqs_[slot].toks.size());
     const size_t n_active = seqs_[slot].active.size();
@@ -82,8 +99,11 @@ class HostTree {
 
       if (ci < 0) {
         if (recs_[ni].count == 1 && ni != 0) {
-          recs_[ni].length += 1;  // a leaf that only this suffix runs through: lengthen its edge
-          mark_node(ni);
+          // a leaf that only this suffix runs through: its edge grows by the new token — implicitly if open
+          if (recs_[ni].length != kOpenLength) {
+            recs_[ni].length += 1;
+            mark_node(ni);
+          }
         } else {
           const int32_t leaf = alloc_node();
           NodeRec& L = recs_[leaf];
@@ -91,11 +111,11 @@ class HostTree {
           L.count = 1;
           L.seq_slot = slot;
           L.start = n_tok - 1;
-          L.length = 1;
+          L.length = kOpenLength;  // one token now, and every token this suffix still receives
           attach_new_kid(ni, token, leaf);
           seqs_[slot].active[i] = leaf;
         }
-      } else if (recs_[ni].count == recs_[ci].count + 1 && ni != 0) {
+      } else if (close_leaf(ci), close_leaf(ni), recs_[ni].count == recs_[ci].count + 1 && ni != 0) {
         if (recs_[ci].length == 1) {
           // the child absorbs `ni` and takes its place under ni's parent
           const int32_t pi = recs_[ni].parent;
@@ -228,6 +248,10 @@ class HostTree {
       }
     }
     if (entries != n_full_) ++bad;
+    for (size_t i = 1; i < recs_.size(); ++i) {
+      if (!recs_[i].alive || recs_[i].length != kOpenLength) continue;
+      if (kids_[i] || recs_[i].count != 1 || len_of(static_cast<int32_t>(i)) < 1) ++bad;
+    }
     return bad;
   }
 
@@ -246,6 +270,8 @@ class HostTree {
     dirty_nodes_.clear();
     for (int32_t i : dirty_slots_) slot_dirty_[i] = 0;
     dirty_slots_.clear();
+    for (int32_t i : dirty_seqs_) seq_dirty_[i] = 0;
+    dirty_seqs_.clear();
     hash_rebuilt_ = false;
   }
   // Reserve (or enlarge) the token-pool region of a sequence so that `need` tokens fit.
@@ -281,6 +307,30 @@ class HostTree {
     return s;
   }
   int tok_at(int32_t slot, int32_t pos) const { return seqs_[slot].toks[pos]; }
+
+  // ---- open leaves -------------------------------------------------------------------------------
+ public:
+  // tokens on the edge into node i (an open leaf's edge runs to the current end of its sequence)
+  int32_t len_of(int32_t i) const {
+    const NodeRec& N = recs_[i];
+    return N.length != kOpenLength ? N.length : static_cast<int32_t>(seqs_[N.seq_slot].toks.size()) - N.start;
+  }
+  std::vector<int32_t>& dirty_seqs() { return dirty_seqs_; }
+
+ private:
+  void close_leaf(int32_t i) {
+    if (recs_[i].length == kOpenLength) {
+      recs_[i].length = len_of(i);
+      mark_node(i);
+    }
+  }
+  void mark_seq(int32_t slot) {
+    if (static_cast<size_t>(slot) >= seq_dirty_.size()) seq_dirty_.resize(slot + 1, 0);
+    if (!seq_dirty_[slot]) {
+      seq_dirty_[slot] = 1;
+      dirty_seqs_.push_back(slot);
+    }
+  }
 
   int32_t find_kid(int32_t ni, int token) const {
     const KidMap* km = kids_[ni];
@@ -446,7 +496,7 @@ class HostTree {
   bool walk(const int32_t* pat, int n, int s, int32_t* out_node, int32_t* out_idx) const {
     int32_t node = 0, idx = 0;
     for (int i = s; i < n; ++i) {
-      if (idx >= recs_[node].length) {
+      if (idx >= len_of(node)) {
         const int32_t c = find_kid(node, pat[i]);
         if (c < 0) return false;
         node = c;
@@ -474,7 +524,7 @@ class HostTree {
       const Pending it = heap.top();
       heap.pop();
       const NodeRec& N = recs_[it.node];
-      if (it.idx < N.length) {
+      if (it.idx < len_of(it.node)) {
         out.token_ids.push_back(tok_at(N.seq_slot, N.start + it.idx));
         out.parents.push_back(it.parent);
         out.probs.push_back(it.prob);
@@ -506,6 +556,8 @@ class HostTree {
 
   std::unordered_map<int, int32_t> slot_of_;
   std::vector<Seq> seqs_;
+  std::vector<uint8_t> seq_dirty_;      // sequences whose length changed since the last mirror (open leaves read it)
+  std::vector<int32_t> dirty_seqs_;
   int32_t pool_end_ = 0;
 };
 

@@ -4,10 +4,12 @@
 //   nodes   : NodeRec[n_nodes]      32 B each (two 16-B loads)
 //   hash    : HashSlot[n_slots]     16 B each, open addressing, linear probing, n_slots = 2^k
 //   tokens  : int32[...]            every sequence owns one contiguous region
-//   seq_base: int32[n_seq_slots]    offset of that region
+//   seq_base: int32[2 * n_seq_slots]  {offset of that region, current length of the sequence} per slot
 //
 // An edge label is (seq_slot, start, length): token j of the edge is
-// tokens[seq_base[seq_slot] + start + j]  (reference: Node{seq_id,start,length}, suffix_tree.h:24-44).
+// tokens[seq_base[2 * seq_slot] + start + j]  (reference: Node{seq_id,start,length}, suffix_tree.h:24-44).
+// length == -1 marks an OPEN leaf (suffix_host.hpp): its edge runs to the end of its sequence,
+// length = seq_base[2 * seq_slot + 1] - start.
 #pragma once
 
 #include <cstdint>
@@ -25,7 +27,7 @@ struct NodeRec {
   int32_t parent;    // -1 for the root
   int32_t seq_slot;  // dense sequence slot of the edge label
   int32_t start;     // first token of the label in that sequence
-  int32_t length;    // tokens on the edge into this node (0 for the root)
+  int32_t length;    // tokens on the edge into this node (0 for the root; -1 = open leaf, see above)
   int32_t best;      // child the reference's "most frequent child" scan would pick, -1 if none
   int32_t alive;     // 0 for a released slot
   int32_t pad;

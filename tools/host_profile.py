@@ -1,15 +1,57 @@
-"""cProfile of the engine's host side over a few bench steps (GPU box): where the Python time of a step goes."""
+#!/usr/bin/env python3
+"""cProfile of the engine's host side on the bench workload (which Python / ctypes calls the step's host chain spends
+its time in).  usage: python tools/host_profile.py [steps]"""
 import cProfile
+import os
 import pstats
 import sys
-import os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench
 
-sys.argv = ["bench.py", "--no-cpu-baseline", "--steps", "32", "--warmup", "8"]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from arcticinference_amd.engine import HotPathEngine, ModelShape, SpecConfig
+from arcticinference_amd.workload import TokenSource
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+B, PL, GL = 64, 4096, 256
+shape, spec = ModelShape(), SpecConfig()
+src = TokenSource(seed=0)
+eng = HotPathEngine(shape, spec, B, PL + GL + 64, None, device="cuda", seed=0)
+pool = [src.stream(PL + GL + 128, r) for r in range(B + 40)]
+nxt = [B]
+streams = {r: pool[r] for r in range(B)}
+eng.add_requests(list(range(B)), list(range(B)), [pool[r][:PL] for r in range(B)],
+                 [pool[r][PL:PL + (r * GL) // B + 1] for r in range(B)])
+
+
+def truth(r, n):
+    s = streams[r.req_id]
+    p = len(r.tokens)
+    return s[p:p + n]
+
+
+def run_step():
+    emitted = eng.step(truth)
+    for slot, r in enumerate(eng.requests):
+        if len(r.tokens) - r.num_prompt >= GL:
+            rid = nxt[0]
+            nxt[0] += 1
+            streams[rid] = pool[rid]
+            eng.add_request(slot, rid, pool[rid][:PL], pool[rid][PL:PL + 1])
+
+
+for _ in range(8):
+    run_step()
+import gc
+gc.collect()
+gc.freeze()
 pr = cProfile.Profile()
 pr.enable()
-bench.main()
+for _ in range(steps):
+    run_step()
 pr.disable()
+torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("cumulative").print_stats(45)
+st.sort_stats("tottime").print_stats(28)
+print({k: round(v / (steps + 8) * 1e3, 3) for k, v in eng.timeline.items()})
