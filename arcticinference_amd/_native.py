@@ -114,6 +114,10 @@ _SIGNATURES = {
     "aic_verify_attention": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
                                      c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_int, c_float, c_void_p, c_int64, c_void_p, c_size_t, c_int, c_void_p]),
+    "aic_verify_attention_layers": (c_int, [c_void_p, c_int64, c_int64, POINTER(c_void_p), POINTER(c_void_p), c_int, c_int64,
+                                            c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                                            c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_int64,
+                                            c_void_p, c_size_t, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "aic_verify_attention_ex": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
                                         c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_float, c_void_p, c_int64, c_void_p, c_size_t, c_int, c_void_p, c_int,

@@ -631,7 +631,15 @@ static void release_image(aic_suffix_tree* t) {
 
 struct aic_suffix_cache {
   explicit aic_suffix_cache(int depth) : max_depth(depth), global(new aic_suffix_tree(depth)) {}
+  // evicted prompt trees are destroyed by a detached-from-the-engine host thread; at most one is in flight
+  std::thread reaper;
+  void retire(std::unique_ptr<aic_suffix_tree> t) {
+    if (reaper.joinable()) reaper.join();
+    aic_suffix_tree* raw = t.release();
+    reaper = std::thread([raw]() { delete raw; });
+  }
   ~aic_suffix_cache() {
+    if (reaper.joinable()) reaper.join();
     // trees hand their buffers back to `pool` before the pool frees them
     for (auto& kv : prompts) {
       kv.second->join_build();
@@ -858,7 +866,9 @@ int aic_sc_evict_prompt(aic_suffix_cache* c, int64_t req) {
     return AIC_ERR_NOT_FOUND;
   }
   it->second->join_build();
-  release_image(it->second.get());
+  release_image(it->second.get());   // device buffers go back to the pool now (the next prompt tree reuses them)
+  // tearing down the host arena (thousands of small maps) costs ~0.5 ms: done on a host thread, off the engine thread
+  c->retire(std::move(it->second));
   c->prompts.erase(it);
   return AIC_OK;
 }

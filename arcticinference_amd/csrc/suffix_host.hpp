@@ -84,7 +84,9 @@ class HostTree {
       recs_[0].count += 1;
       mark_node(0);
       if (s0.active.size() > static_cast<size_t>(max_depth_)) {
-        close_leaf(s0.active.front());  // its suffix stops growing here: the edge ends at the sequence's current end
+        // its suffix stops growing here: the edge ends at the sequence's current end
+        const int32_t oldest = s0.active.front();
+        close_leaf(oldest < 0 ? ~oldest : oldest);
         s0.active.pop_front();
       }
       s0.toks.push_back(token);
@@ -94,7 +96,12 @@ class HostTree {
     const size_t n_active = seqs_[slot].active.size();
 
     for (size_t i = 0; i < n_active; ++i) {
-      const int32_t ni = seqs_[slot].active[i];
+      // an active entry < 0 is ~(index of an OPEN leaf this suffix owns): the token lengthens it implicitly, and the
+      // node record is not even read (most of the <= max_depth entries are such leaves; on a tree that has gone cold
+      // between two engine steps every record read is a cache miss)
+      const int32_t entry = seqs_[slot].active[i];
+      if (entry < 0) continue;
+      const int32_t ni = entry;
       const int32_t ci = find_kid(ni, token);
 
       if (ci < 0) {
@@ -113,7 +120,7 @@ class HostTree {
           L.start = n_tok - 1;
           L.length = kOpenLength;  // one token now, and every token this suffix still receives
           attach_new_kid(ni, token, leaf);
-          seqs_[slot].active[i] = leaf;
+          seqs_[slot].active[i] = ~leaf;
         }
       } else if (close_leaf(ci), close_leaf(ni), recs_[ni].count == recs_[ci].count + 1 && ni != 0) {
         if (recs_[ci].length == 1) {
@@ -248,10 +255,23 @@ class HostTree {
       }
     }
     if (entries != n_full_) ++bad;
+    size_t n_open = 0, n_owned = 0;
     for (size_t i = 1; i < recs_.size(); ++i) {
       if (!recs_[i].alive || recs_[i].length != kOpenLength) continue;
+      ++n_open;
       if (kids_[i] || recs_[i].count != 1 || len_of(static_cast<int32_t>(i)) < 1) ++bad;
     }
+    // every open leaf is owned by exactly one active suffix of its own sequence, tagged ~index
+    for (size_t k = 0; k < seqs_.size(); ++k)
+      for (int32_t e : seqs_[k].active)
+        if (e < 0) {
+          ++n_owned;
+          const int32_t i = ~e;
+          if (i <= 0 || static_cast<size_t>(i) >= recs_.size() || !recs_[i].alive || recs_[i].length != kOpenLength ||
+              recs_[i].seq_slot != static_cast<int32_t>(k))
+            ++bad;
+        }
+    if (n_open != n_owned) ++bad;
     return bad;
   }
 
@@ -322,6 +342,12 @@ class HostTree {
     if (recs_[i].length == kOpenLength) {
       recs_[i].length = len_of(i);
       mark_node(i);
+      // its owner (an active suffix of the leaf's own sequence) goes back to the explicit bookkeeping
+      for (int32_t& e : seqs_[recs_[i].seq_slot].active)
+        if (e == ~i) {
+          e = i;
+          break;
+        }
     }
   }
   void mark_seq(int32_t slot) {

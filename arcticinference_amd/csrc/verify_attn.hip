@@ -1414,6 +1414,31 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   return launch_status("verify_attn_combine_kernel");
 }
 
+// The same call for a run of layers that share the step's geometry (one engine step of a stand-alone driver: q / out
+// advance by a fixed stride per layer or stay, the caches come from pointer tables): one foreign call instead of one per
+// layer.  q_layer_stride / out_layer_stride are in elements (0 = every layer reads the same q / writes the same out).
+int aic_verify_attention_layers(const void* q, int64_t q_stride, int64_t q_layer_stride, const void* const* k_caches,
+                                const void* const* v_caches, int n_layers, int64_t block_stride, int kv_dtype,
+                                const float* k_scale, const float* v_scale, const int32_t* block_table,
+                                int max_blocks_per_seq, const int32_t* seq_lens, const int32_t* query_start_loc, int batch,
+                                int num_tokens, int max_q_len, int num_q_heads, int num_kv_heads, int head_size,
+                                int block_size, float sm_scale, void* out, int64_t out_stride, int64_t out_layer_stride,
+                                void* workspace, size_t workspace_bytes, int max_seq_len, const int32_t* short_reqs,
+                                int n_short, const int32_t* long_reqs, int n_long, void* stream) {
+  AIC_REQUIRE(n_layers >= 0 && (n_layers == 0 || (k_caches && v_caches)), "bad layer tables");
+  for (int l = 0; l < n_layers; ++l) {
+    const uint16_t* ql = static_cast<const uint16_t*>(q) + static_cast<int64_t>(l) * q_layer_stride;
+    uint16_t* ol = static_cast<uint16_t*>(out) + static_cast<int64_t>(l) * out_layer_stride;
+    const int rc = aic_verify_attention_ex(ql, q_stride, k_caches[l], v_caches[l], block_stride, kv_dtype, k_scale, v_scale,
+                                           block_table, max_blocks_per_seq, seq_lens, query_start_loc, batch, num_tokens,
+                                           max_q_len, num_q_heads, num_kv_heads, head_size, block_size, sm_scale, ol,
+                                           out_stride, workspace, workspace_bytes, max_seq_len, short_reqs, n_short,
+                                           long_reqs, n_long, stream);
+    if (rc != AIC_OK) return rc;
+  }
+  return AIC_OK;
+}
+
 int aic_verify_attention(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
                          int64_t block_stride, int kv_dtype, const float* k_scale, const float* v_scale,
                          const int32_t* block_table, int max_blocks_per_seq, const int32_t* seq_lens,

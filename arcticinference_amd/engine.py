@@ -517,7 +517,12 @@ class HotPathEngine:
             plan = ops.VerifyAttentionPlan(q, out, self.kv[0][0], bt, d_seq, d_qsl, max_q, max_ctx, self.sm_scale,
                                            req_split=self._req_split, k_scale=self.kv_scale, v_scale=self.kv_scale,
                                            stream=self._stream)
-            for kv in self.kv:
-                plan.run(kv[0], kv[1])
+            plan.run_layers(self.layer_tables(plan))     # all layers: one foreign call
         else:
             self.ulysses.attention_layers(self, T, bt, d_seq, d_qsl, max_q, max_ctx)
+
+    def layer_tables(self, plan):
+        """Pointer tables of the per-layer K / V caches (fixed for the engine's life)."""
+        if not hasattr(self, "_layer_tables"):
+            self._layer_tables = plan.layer_tables([kv[0] for kv in self.kv], [kv[1] for kv in self.kv])
+        return self._layer_tables

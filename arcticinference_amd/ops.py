@@ -231,6 +231,22 @@ class VerifyAttentionPlan:
                       N.current_stream_ptr() if stream is None else stream]
         self._kv_shape, self._kv_dtype, self._kv_stride = tuple(kv_like.shape), kv_like.dtype, kv_like.stride(0)
 
+    def layer_tables(self, k_caches: Sequence[torch.Tensor], v_caches: Sequence[torch.Tensor]):
+        """Pointer tables for run_layers() (build once for a fixed set of caches)."""
+        for c in list(k_caches) + list(v_caches):
+            if c.shape != self._kv_shape or c.dtype is not self._kv_dtype or c.stride(0) != self._kv_stride:
+                raise ValueError("the plan was made for caches of another shape / dtype")
+        VP = ctypes.c_void_p * len(k_caches)
+        return (VP(*[c.data_ptr() for c in k_caches]), VP(*[c.data_ptr() for c in v_caches]), len(k_caches),
+                (list(k_caches), list(v_caches)))
+
+    def run_layers(self, tables) -> None:
+        """Every layer of the step in ONE foreign call (aic_verify_attention_layers): same q / out for all layers, as
+        the stand-alone engine has them."""
+        a = self._args
+        kt, vt, n, _keep = tables
+        N.check(N.lib().aic_verify_attention_layers(a[0], a[1], 0, kt, vt, n, *a[4:20], a[20], a[21], 0, *a[22:]))
+
     def run(self, k_cache: torch.Tensor, v_cache: torch.Tensor) -> None:
         if k_cache.shape != self._kv_shape or k_cache.dtype is not self._kv_dtype or k_cache.stride(0) != self._kv_stride:
             raise ValueError("the plan was made for caches of another shape / dtype")

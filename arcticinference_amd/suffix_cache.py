@@ -131,7 +131,10 @@ class SuffixCache:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            N.lib().aic_sc_destroy(self._h)
+            try:
+                N.lib().aic_sc_destroy(self._h)
+            except TypeError:       # interpreter shutdown: the module globals are already gone
+                pass
             self._h = None
 
     def _key(self, req_id: Hashable) -> int:

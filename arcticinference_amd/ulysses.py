@@ -289,8 +289,7 @@ class UlyssesContext:
             plan = ops.VerifyAttentionPlan(q_loc, out, eng.kv[0][0], bt, d_seq, d_qsl, max_q, max_ctx, eng.sm_scale,
                                            req_split=eng._req_split, k_scale=eng.kv_scale, v_scale=eng.kv_scale,
                                            stream=eng._stream)
-            for kv in eng.kv:
-                plan.run(kv[0], kv[1])
+            plan.run_layers(eng.layer_tables(plan))
             return
         self.steps_sp += 1
         # this rank's token slice x all heads, as the dense layers of the target would hand it over

@@ -332,6 +332,18 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
                             void* out, int64_t out_stride, void* workspace, size_t workspace_bytes,
                             int max_seq_len, const int32_t* short_reqs, int n_short, const int32_t* long_reqs,
                             int n_long, void* stream);
+/* aic_verify_attention_ex for `n_layers` layers of one engine step in one call: k_caches / v_caches are HOST arrays of
+ * device pointers (one cache pair per layer, same shape / dtype / strides), q and out advance by *_layer_stride elements
+ * per layer (0: shared).  For drivers that own the whole step (arcticinference_amd/engine.py); inside vLLM attention is
+ * called per layer. */
+int aic_verify_attention_layers(const void* q, int64_t q_stride, int64_t q_layer_stride, const void* const* k_caches /*host*/,
+                                const void* const* v_caches /*host*/, int n_layers, int64_t block_stride, int kv_dtype,
+                                const float* k_scale, const float* v_scale, const int32_t* block_table,
+                                int max_blocks_per_seq, const int32_t* seq_lens, const int32_t* query_start_loc, int batch,
+                                int num_tokens, int max_q_len, int num_q_heads, int num_kv_heads, int head_size,
+                                int block_size, float sm_scale, void* out, int64_t out_stride, int64_t out_layer_stride,
+                                void* workspace, size_t workspace_bytes, int max_seq_len, const int32_t* short_reqs,
+                                int n_short, const int32_t* long_reqs, int n_long, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * A12  Ulysses head/sequence repartition — the copies around the two all-to-alls of

@@ -333,6 +333,13 @@ def test_verify_attention_plan_equals_direct_call():
     assert torch.equal(out, want)
     with pytest.raises(ValueError):
         plan.run(dk[:-1], dv[:-1])
+    # every layer of a step in one foreign call: the last layer's result stays in `out`
+    k3, v3 = torch.randn_like(dk), torch.randn_like(dv)
+    want3 = ops.verify_attention(dq, k3, v3, dbt, seq, dqsl, max(q_lens), max(ctxs), D ** -0.5, req_split=rs)
+    plan.run_layers(plan.layer_tables([dk, k2, k3], [dv, v2, v3]))
+    assert torch.equal(out, want3)
+    with pytest.raises(ValueError):
+        plan.layer_tables([dk[:-1]], [dv[:-1]])
 
 
 def test_verify_attention_unsupported_shapes():
