@@ -239,23 +239,19 @@ __device__ __forceinline__ void softmax_tile_long(const f32x4& s0, const f32x4& 
   }
 }
 
-// 8 e4m3 bytes (two dwords) -> 8 bf16 (exact: every e4m3 value is a bf16 value)
+// 8 e4m3 bytes (two dwords) -> 8 bf16 (exact: every e4m3 value is a bf16 value).  gfx950's scaled converts take two
+// fp8 to two bf16 in ONE instruction (v_cvt_scalef32_pk_bf16_fp8, scale 1.0): 4 VALU per 8 elements where the
+// fp8 -> f32 -> bf16 route took 8.  SQ counters on the fp8 short body (profiles/r02_pmc_secondary_kernels.txt): 70.8 % of
+// its wave cycles were instruction issue (bf16 body: 32 %), 1.15e8 VALU instructions for half the bytes of the bf16
+// body's 8.3e7 — the conversion made it issue-bound.
 __device__ __forceinline__ bf16x8 fp8x8_to_bf16x8(uint32_t lo, uint32_t hi) {
-  typedef __attribute__((ext_vector_type(2))) float f32x2;
-  const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(static_cast<int>(lo), false);
-  const f32x2 b = __builtin_amdgcn_cvt_pk_f32_fp8(static_cast<int>(lo), true);
-  const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(static_cast<int>(hi), false);
-  const f32x2 d = __builtin_amdgcn_cvt_pk_f32_fp8(static_cast<int>(hi), true);
-  bf16x8 r;
-  r[0] = static_cast<__bf16>(a[0]);
-  r[1] = static_cast<__bf16>(a[1]);
-  r[2] = static_cast<__bf16>(b[0]);
-  r[3] = static_cast<__bf16>(b[1]);
-  r[4] = static_cast<__bf16>(c[0]);
-  r[5] = static_cast<__bf16>(c[1]);
-  r[6] = static_cast<__bf16>(d[0]);
-  r[7] = static_cast<__bf16>(d[1]);
-  return r;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  const bf16x2_t a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(static_cast<int>(lo), 1.0f, false);
+  const bf16x2_t b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(static_cast<int>(lo), 1.0f, true);
+  const bf16x2_t c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(static_cast<int>(hi), 1.0f, false);
+  const bf16x2_t d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(static_cast<int>(hi), 1.0f, true);
+  return __builtin_shufflevector(__builtin_shufflevector(a, b, 0, 1, 2, 3), __builtin_shufflevector(c, d, 0, 1, 2, 3), 0, 1,
+                                 2, 3, 4, 5, 6, 7);
 }
 
 // Rows written by a launch with fewer splits than the call's slot count mark their unused slots empty, so the

@@ -188,6 +188,16 @@ if __name__ == "__main__":
         attn(B=16, qlen=17, split=True)
         attn(B=5, qlen=33, split=True)
         attn(B=1, qlen=33, split=True)
+    if "pmc" in what:      # the cases whose kernels tools/pmc_kernels.py tells apart by name (few iterations: counters, not time)
+        _t = timeit
+        timeit = lambda fn, iters=4, warm=1: _t(fn, iters=4, warm=1)
+        attn(split=True)                               # verify_attn_kernel<1, true, false, 4>: the bf16 short body (baseline)
+        attn(split=True, kv8=True)                     # <1, true, true, 4>: fp8 short body
+        attn(B=64, Hq=4, Hkv=1, split=True)            # <1, false, false, 4>: SP = 8 slice, waves = token ranges
+        attn(B=16, qlen=33, split=True)                # verify_attn_long4_kernel<false, 128>: long drafts alone
+        attn(B=16, qlen=33, split=True, kv8=True)      # verify_attn_long4_kernel<true, 128>
+        attn(B=64, Hq=64, Hkv=8, D=64)                 # verify_attn_long4_kernel<false, 64>: head size 64
+        timeit = _t
     if "trace" in what:
         attn_trace(59, 5)
         attn_trace(56, 8)
