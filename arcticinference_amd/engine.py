@@ -224,17 +224,58 @@ class HotPathEngine:
         """`next_truth(req, n)` -> the target model's greedy tokens for the next n positions of `req`
         (the synthetic target: its verify logits get these tokens planted as arg-max).
         Returns the tokens emitted per live request."""
+        ctx = self.begin(next_truth)
+        return [] if ctx is None else self.finish(ctx)
+
+    # A step has a device half and a host half.  begin() builds the step's geometry and enqueues everything the GPU does
+    # (KV write, attention, acceptance, accepted tokens on their way to the host); finish() waits for the accepted
+    # tokens and runs the host chain (parse, tree updates, suffix proposal, merge).  Called back to back they are one
+    # step.  A driver may also split the live requests into two LANES (disjoint slot sets, each with its own staging
+    # buffers and events) and interleave them — begin(A); finish(B); begin(B); finish(A); ... — so that one lane's
+    # host chain runs while the GPU attends for the other (bench.py --lanes 2).  Each lane is then its own sequence of
+    # engine steps over its requests: the reference's per-step rules (update all, then propose; the draft-model merge
+    # rule) apply per lane step, as they would if vLLM had scheduled those requests in that step.
+    def _lane(self, lane: int):
+        lanes = self.__dict__.setdefault("_lanes", {})
+        if lane not in lanes:
+            from types import SimpleNamespace
+            L = SimpleNamespace(stage={}, out_pin=None, out_ev=None, lstm_prev=None, lstm_pin=None, lstm_flip=0,
+                                suffix_won_last=False)
+            # pinned buffers are allocated here, not at first use: hipHostMalloc takes milliseconds, and a lane's first
+            # draft-model step may come long after its first step
+            L.out_pin = torch.empty(self.max_num_seqs * (MAX_SPEC_LEN + 2), dtype=torch.int32).pin_memory()
+            L.out_ev = torch.cuda.Event()
+            if self.drafter is not None:
+                k = self.spec.num_speculative_tokens
+                L.lstm_pin = [torch.empty(self.max_num_seqs, k, dtype=torch.int64).pin_memory() for _ in range(2)]
+                # the device-side fill of pending draft ids uses torch kernels nothing else here uses; their first launch
+                # loads the code object (tens of ms, measured inside a 20-step bench): do it now
+                idx = torch.zeros(2, dtype=torch.int64, device=self.device)
+                torch.zeros(4, dtype=torch.int32, device=self.device).index_copy_(
+                    0, idx, torch.zeros(4, dtype=torch.int64, device=self.device).index_select(0, idx).to(torch.int32))
+            for which in ("A", "B"):
+                pin = torch.empty(1 << 17, dtype=torch.uint8).pin_memory()
+                L.stage[which] = (pin, torch.empty(pin.numel(), dtype=torch.uint8, device=self.device))
+            lanes[lane] = L
+        return lanes[lane]
+
+    def begin(self, next_truth, only_slots: Optional[Sequence[int]] = None, lane: int = 0):
+        """Device half of a step over the live requests (of `only_slots`, default all).  Returns the step's context for
+        finish(), or None when there is nothing to do."""
+        from types import SimpleNamespace
         import time as _t
         _t0 = _t.perf_counter()
         def _mark(name, _state=[_t0]):
             now = _t.perf_counter()
             self.timeline[name] = self.timeline.get(name, 0.0) + (now - _state[0])
             _state[0] = now
+        L = self._lane(lane)
         s, spec, dev = self.shape, self.spec, self.device
-        live = [i for i, r in enumerate(self.requests) if r is not None]
+        cand = range(len(self.requests)) if only_slots is None else only_slots
+        live = [i for i in cand if self.requests[i] is not None]
         B = len(live)
         if B == 0:
-            return []
+            return None
         reqs = [self.requests[i] for i in live]
         n_draft = np.fromiter((len(r._drafts) for r in reqs), dtype=np.int32, count=B)
         q_len = n_draft + 1
@@ -254,7 +295,7 @@ class HotPathEngine:
         G = self.hq_local // self.hkv_local
         so = ops.split_order(q_len, G)            # short / long request lists of the attention call
         order = so[0] if so is not None else np.zeros(0, np.int32)
-        stA = self._stage("A", [(ctx, np.int32), (qsl, np.int32), (np.asarray(live), np.int64), (slot_map, np.int64),
+        stA = self._stage(L, "A", [(ctx, np.int32), (qsl, np.int32), (np.asarray(live), np.int64), (slot_map, np.int64),
                                 (order, np.int32)])
         d_seq, d_qsl, slots, d_slots, order_dev = stA
         bt = self.block_table.index_select(0, slots) if B != self.max_num_seqs else self.block_table
@@ -280,7 +321,7 @@ class HotPathEngine:
         draft_flat = np.fromiter(itertools.chain.from_iterable(r._drafts for r in reqs), dtype=np.int32, count=n_draft_total)
         cu_draft = np.cumsum(n_draft)
         fill_pos = fill_src = np.zeros(0, np.int64)
-        prev_lstm = getattr(self, "_lstm_prev", None)
+        prev_lstm = L.lstm_prev
         if prev_lstm is not None:
             pend_rows = np.fromiter((r.draft_row if (r._pending is not None and not r._pending.done) else -1 for r in reqs),
                                     dtype=np.int64, count=B)
@@ -297,7 +338,7 @@ class HotPathEngine:
         target_rows = np.nonzero(~is_bonus)[0]
         bonus_rows = qsl[1:] - 1
         d_draft, d_cu, d_plant, d_trows, d_brows, d_fpos, d_fsrc = self._stage(
-            "B", [(draft_flat, np.int32), (cu_draft, np.int32), (plant_tok, np.int64), (target_rows, np.int64),
+            L, "B", [(draft_flat, np.int32), (cu_draft, np.int32), (plant_tok, np.int64), (target_rows, np.int64),
                   (bonus_rows, np.int64), (fill_pos, np.int64), (fill_src, np.int64)])
         # the LSTM draft ids of the previous step (still on the device) go into this step's draft array
         if len(fill_pos):
@@ -317,12 +358,9 @@ class HotPathEngine:
         # (d) accepted tokens start their way to the host (pinned buffer, event) BEFORE the LSTM draft is
         # enqueued: the draft needs nothing from the host (last token / hidden row come from the acceptance
         # kernel on the device), so it runs while the host parses tokens and updates the suffix trees
-        if not hasattr(self, "_out_pin"):
-            self._out_pin = torch.empty(self.max_num_seqs * (MAX_SPEC_LEN + 2), dtype=torch.int32).pin_memory()
-            self._out_ev = torch.cuda.Event()
-        out_pin = self._out_pin[:B * (max_spec + 1)].view(B, max_spec + 1)   # contiguous: a strided pinned target makes the copy blocking
+        out_pin = L.out_pin[:B * (max_spec + 1)].view(B, max_spec + 1)   # contiguous: a strided pinned target makes the copy blocking
         out_pin.copy_(rej.output_token_ids, non_blocking=True)
-        self._out_ev.record()
+        L.out_ev.record()
         lstm_out = None
         use_lstm = spec.method in ("arctic", "mlp_speculator") and self.drafter is not None and B <= spec.disable_by_batch_size
         # Under the reference's rule (SpecConfig.draft_model_per_request = False) the draft model's output is dropped
@@ -330,13 +368,26 @@ class HotPathEngine:
         # Steps follow each other closely in what they do, so: if the previous step used the draft model, enqueue it
         # now (it runs while the host updates the trees) and drop it should suffix decoding win; if the previous step
         # was taken by suffix decoding, wait for the suffix result and run the draft model only if nobody was taken.
-        early_lstm = use_lstm and (spec.draft_model_per_request or self.suffix_cache is None or
-                                   not getattr(self, "_suffix_won_last", False))
+        early_lstm = use_lstm and (spec.draft_model_per_request or self.suffix_cache is None or not L.suffix_won_last)
         if early_lstm:
             lstm_out = self.drafter.generate_proposals(rej.last_token, self.hidden, spec.num_speculative_tokens,
                                                        hidden_index=rej.hidden_index)
         _mark('enqueue_accept_and_draft')
-        self._out_ev.synchronize()                       # the step's only blocking wait before the proposals
+        return SimpleNamespace(lane=L, live=live, reqs=reqs, B=B, n_draft=n_draft, out_pin=out_pin, rej=rej, lstm_out=lstm_out,
+                               use_lstm=use_lstm)
+
+    def finish(self, c) -> List[List[int]]:
+        """Host half of the step begun as `c`: returns the tokens emitted per request of that step."""
+        import time as _t
+        _t0 = _t.perf_counter()
+        def _mark(name, _state=[_t0]):
+            now = _t.perf_counter()
+            self.timeline[name] = self.timeline.get(name, 0.0) + (now - _state[0])
+            _state[0] = now
+        s, spec, dev = self.shape, self.spec, self.device
+        L, live, reqs, B, n_draft, out_pin, rej, lstm_out, use_lstm = (c.lane, c.live, c.reqs, c.B, c.n_draft, c.out_pin, c.rej,
+                                                                      c.lstm_out, c.use_lstm)
+        L.out_ev.synchronize()                           # the step's only blocking wait before the proposals
         out_host = out_pin.numpy()
         _mark('wait_gpu_accept')
 
@@ -382,7 +433,7 @@ class HotPathEngine:
         if suffix is not None:
             took = (suffix[1] > 0) & (suffix[2] >= min_score)
         suffix_won = bool(took is not None and took.any())
-        self._suffix_won_last = suffix_won
+        L.suffix_won_last = suffix_won
         if use_lstm and not spec.draft_model_per_request:
             if suffix_won:
                 self.stats.draft_model_dropped += lstm_out is not None
@@ -394,17 +445,16 @@ class HotPathEngine:
         self.stats.steps += 1
         self.stats.draft_model_steps += lstm_out is not None
         if lstm_out is not None:
-            if not hasattr(self, "_lstm_pin"):
-                self._lstm_pin = [torch.empty(self.max_num_seqs, lstm_out.shape[1], dtype=lstm_out.dtype).pin_memory()
-                                  for _ in range(2)]
-                self._lstm_flip = 0
-            self._lstm_flip ^= 1
-            pin = self._lstm_pin[self._lstm_flip][:B]      # two buffers: the previous step's copy may still be unread
+            if L.lstm_pin is None or L.lstm_pin[0].shape[1] != lstm_out.shape[1]:
+                L.lstm_pin = [torch.empty(self.max_num_seqs, lstm_out.shape[1], dtype=lstm_out.dtype).pin_memory()
+                              for _ in range(2)]
+            L.lstm_flip ^= 1
+            pin = L.lstm_pin[L.lstm_flip][:B]              # two buffers: the previous step's copy may still be unread
             pin.copy_(lstm_out, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
             pend = _PendingDrafts(pin, ev, [])
-        self._lstm_prev = lstm_out
+        L.lstm_prev = lstm_out
         _mark('host_draft_copy')
         # the draft model's length clamp is ONE value for the batch in the reference (the running minimum of
         # propose_arctic_draft_token_ids, model_runner.py:629-641); the per-request extension clamps per request
@@ -430,9 +480,10 @@ class HotPathEngine:
     # -- pieces -------------------------------------------------------------------------------------------
     _TORCH_OF = {np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64}
 
-    def _stage(self, which: str, arrays):
-        """One pinned buffer + ONE host->device copy for a group of small index arrays; returns their device views."""
-        bufs = self.__dict__.setdefault("_stage_bufs", {})
+    def _stage(self, lane, which: str, arrays):
+        """One pinned buffer + ONE host->device copy for a group of small index arrays; returns their device views.
+        Buffers belong to a lane: a lane's previous copy has completed (its step was finished) before it stages again."""
+        bufs = lane.stage
         offs, nbytes = [], 0
         for a, k in arrays:
             nbytes = (nbytes + 15) & ~15

@@ -125,3 +125,53 @@ def test_engine_runs_to_the_model_length_limit(method, with_lstm):
             assert toks == [int(x) for x in s[before[r.req_id]:before[r.req_id] + len(toks)]]
             assert len(r.tokens) + r.num_drafts <= limit, "a draft may not reach past the last position"
     assert finished == 4
+
+
+@pytest.mark.parametrize("method,with_lstm", [("suffix", False), ("arctic", True)])
+def test_two_interleaved_lanes_follow_the_reference_policy_per_lane_step(method, with_lstm):
+    """begin() / finish() with two lanes (bench.py --lanes 2): lane A's host half runs after lane B's device half has been
+    enqueued.  Every lane step is an engine step over that lane's requests: emitted tokens are the target's, and the
+    drafts are what the oracle policy gives when it sees the same sequence of updates (lane by lane)."""
+    from arcticinference_amd.workload import TokenSource
+    from arcticinference_amd.vllm_plugin.runner_logic import MAX_SPEC_LEN
+    eng, spec = _build(method, with_lstm)
+    src = TokenSource(vocab_size=2000, seed=5, n_motifs=3, motif_min=8, motif_max=16, p_motif=0.9)
+    B, PL = 4, 96
+    streams = {r: src.stream(PL + 200, r) for r in range(B)}
+    eng.add_requests(list(range(B)), list(range(B)), [streams[r][:PL] for r in range(B)], [int(streams[r][PL]) for r in range(B)])
+    orc = OracleSuffixCache(spec.suffix_cache_max_depth)
+    for r in range(B):
+        orc.cache_prompt(r, [int(x) for x in streams[r][:PL]])
+        orc.update_response(r, [int(streams[r][PL])])
+    truth = lambda req, n: streams[req.req_id][len(req.tokens):len(req.tokens) + n]
+    min_score = 0 if method == "suffix" else spec.num_speculative_tokens
+    lanes = [[0, 2], [1, 3]]
+    pending = [None, None]
+    used_suffix = used_lstm = 0
+    for rnd in range(24):
+        for l in (0, 1):
+            c = pending[l]
+            if c is not None:
+                before = [len(r.tokens) for r in c.reqs]
+                emitted = eng.finish(c)
+                for r, toks, b0 in zip(c.reqs, emitted, before):
+                    assert toks == [int(x) for x in streams[r.req_id][b0:b0 + len(toks)]]
+                    orc.update_response(r.req_id, toks)
+                wants = [orc.speculate(r.req_id, r.tokens[-64:], max_spec_tokens=min(MAX_SPEC_LEN, 64, 400 - len(r.tokens) - 1))
+                         for r in c.reqs]
+                takes = [bool(w.score >= min_score and w.token_ids) for w in wants]
+                for r, w, t in zip(c.reqs, wants, takes):
+                    if t:
+                        assert r.drafts == w.token_ids
+                        used_suffix += 1
+                    elif with_lstm and not any(takes):
+                        assert len(r.drafts) == 3
+                        used_lstm += 1
+                    else:
+                        assert r.drafts == []
+            pending[l] = eng.begin(truth, lanes[l], lane=l)
+            assert [eng.requests[i] for i in lanes[l]] == pending[l].reqs
+    assert used_suffix > 10 and (used_lstm > 0 or not with_lstm)
+    for c in pending:
+        eng.finish(c)
+    assert eng.suffix_cache._global_tree().selfcheck() == 0

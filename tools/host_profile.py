@@ -14,6 +14,7 @@ from arcticinference_amd.engine import HotPathEngine, ModelShape, SpecConfig
 from arcticinference_amd.workload import TokenSource
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+n_lanes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 B, PL, GL = 64, 4096, 256
 shape, spec = ModelShape(), SpecConfig()
 src = TokenSource(seed=0)
@@ -31,14 +32,22 @@ def truth(r, n):
     return s[p:p + n]
 
 
+lane_slots = [list(range(l, B, n_lanes)) for l in range(n_lanes)]
+pending = [None] * n_lanes
+
+
 def run_step():
-    emitted = eng.step(truth)
-    for slot, r in enumerate(eng.requests):
-        if len(r.tokens) - r.num_prompt >= GL:
-            rid = nxt[0]
-            nxt[0] += 1
-            streams[rid] = pool[rid]
-            eng.add_request(slot, rid, pool[rid][:PL], pool[rid][PL:PL + 1])
+    for l in range(n_lanes):
+        if pending[l] is not None:
+            eng.finish(pending[l])
+            for slot in lane_slots[l]:
+                r = eng.requests[slot]
+                if len(r.tokens) - r.num_prompt >= GL:
+                    rid = nxt[0]
+                    nxt[0] += 1
+                    streams[rid] = pool[rid]
+                    eng.add_request(slot, rid, pool[rid][:PL], pool[rid][PL:PL + 1])
+        pending[l] = eng.begin(truth, lane_slots[l] if n_lanes > 1 else None, lane=l)
 
 
 for _ in range(8):
@@ -53,5 +62,5 @@ for _ in range(steps):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(28)
+st.sort_stats("tottime").print_stats(22)
 print({k: round(v / (steps + 8) * 1e3, 3) for k, v in eng.timeline.items()})
