@@ -92,6 +92,7 @@ _SIGNATURES = {
     "aic_ulysses_pack_pair": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "aic_ulysses_reorder_split_kv": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_int32), c_void_p]),
     "aic_debug_attn_trace": (c_int, [c_void_p, c_int]),
+    "aic_debug_attn_layout": (c_int, [c_int, c_int]),
     "aic_row_gather": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64),
                                POINTER(c_int32), c_void_p, c_int, c_int, c_void_p]),
     "aic_rejection_workspace_bytes": (c_size_t, [c_int, c_int]),

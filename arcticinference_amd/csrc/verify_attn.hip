@@ -71,6 +71,13 @@ struct AttnParams {
   const float* v_scale;
   float sm_scale;
   int dbg;
+  // direct output (this launch's n_splits == 1 and its rows need no cross-workgroup merge): the workgroup that holds a
+  // row's whole context writes the finished bf16 row to out; mark_final = a combine launch follows for other rows of
+  // the call and must skip these (slot 0 gets the "already final" mark, l = -1)
+  uint16_t* out;
+  int64_t out_stride;
+  int direct;
+  int mark_final;
   int64_t* trace;  // debug (aic_debug_attn_trace): per workgroup {start, end (100 MHz ticks), HW_ID | XCC_ID << 32, kind}
 };
 
@@ -278,15 +285,24 @@ struct ShortLds {
 };
 
 // Body of the short / generic kernel for workgroup (bx, by) of its grid; v_lds_raw = ShortLds<MTQ, NW>::kU4 uint4 of LDS.
-template <int MTQ, bool WH, bool KV8, int NW>
+// HPW = kv heads per workgroup (NW, NW/2 ... 1): the NW waves are HPW groups of R = NW / HPW waves; a group owns one kv
+// head and its R waves take R consecutive token ranges of the workgroup's share, merged through LDS at the end.
+// HPW == NW: every wave its own head (the streaming layout: 1 KiB contiguous per token per workgroup), no merge.
+// Smaller HPW trades that for more workgroups per request WITHOUT cross-workgroup partials: with 64 requests x 8 kv heads,
+// HPW = 2 gives 256 workgroups whose waves stream exactly what the HPW = 4 / two-split form streamed per wave, but the two
+// halves of a head meet in LDS and the finished row goes straight to `out` — no partial write, no combine launch.
+template <int MTQ, int HPW, bool KV8, int NW>
 __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_lds_raw, const int bx, const int by) {
+  constexpr bool WH = HPW == NW;
+  constexpr int R = NW / HPW;   // token ranges (waves) per head inside the workgroup
+  static_assert(NW % HPW == 0, "waves must divide evenly over the heads of a workgroup");
   uint4(*v_lds)[kTile * 16] = reinterpret_cast<uint4(*)[kTile * 16]>(v_lds_raw);
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps loop control scalar
   const int g = lane >> 4, c16 = lane & 15;
   const int Hkv = P.num_kv_heads, Hq = P.num_q_heads, G = Hq / Hkv;
-  const int hgroups = WH ? Hkv / NW : Hkv;
+  const int hgroups = Hkv / HPW;
   // blockIdx.x = ((item / 8) * m_groups + row_group) * 8 + item % 8: the row groups of one (request, heads)
   // item are dispatched back to back AND on the same XCD (workgroups are dealt round-robin over the 8 XCDs),
   // so the extra row groups of a long (suffix) draft re-read their KV through that XCD's L2 instead of HBM;
@@ -297,7 +313,8 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
   if (item >= P.n_items) return;
   const int ridx = item / hgroups;
   const int req = __builtin_amdgcn_readfirstlane(P.req_list ? P.req_list[ridx] : ridx);
-  const int h = WH ? (item - ridx * hgroups) * NW + wave : item - ridx * hgroups;
+  const int head_local = wave / R, range = wave - head_local * R;
+  const int h = (item - ridx * hgroups) * HPW + head_local;
   const int q0 = __builtin_amdgcn_readfirstlane(P.query_start_loc[req]);
   const int q_len = __builtin_amdgcn_readfirstlane(P.query_start_loc[req + 1]) - q0;
   const int ctx = __builtin_amdgcn_readfirstlane(P.seq_lens[req]);
@@ -305,8 +322,8 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
   const int row0 = row_group * (MTQ * 16);
   if (row0 >= n_rows) return;
 
-  const int n_parts = WH ? P.n_splits : P.n_splits * 4;
-  const int part = WH ? by : by * 4 + wave;
+  const int n_parts = P.n_splits * R;
+  const int part = by * R + range;
   const int tiles_total = (ctx + kTile - 1) / kTile;
   const int tiles_per_part = (tiles_total + n_parts - 1) / n_parts;
   const int t_begin = part * tiles_per_part * kTile;
@@ -506,14 +523,35 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
 #undef AIC_V_ADDR
 #undef AIC_STORE_V
 
+  // finished rows (direct mode): normalise, round to bf16, 8 bytes per lane and 16-wide d tile
+  auto store_final = [&](int mt, const f32x4 (&o)[8], float inv_l, int64_t tok, int hq) {
+    uint16_t* op = P.out + tok * P.out_stride + static_cast<int64_t>(hq) * kD + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      const uint32_t lo = static_cast<uint32_t>(f32_to_bf16(o[dt][0] * inv_l)) | (static_cast<uint32_t>(f32_to_bf16(o[dt][1] * inv_l)) << 16);
+      const uint32_t hi = static_cast<uint32_t>(f32_to_bf16(o[dt][2] * inv_l)) | (static_cast<uint32_t>(f32_to_bf16(o[dt][3] * inv_l)) << 16);
+      *reinterpret_cast<uint2*>(op + dt * 16) = make_uint2(lo, hi);
+    }
+  };
+  auto mark_row_final = [&](int64_t grow) {   // tells the combine launch of a mixed call to leave this row alone
+    float* mp = P.ws_ml + grow * 2;
+    mp[0] = -INFINITY;
+    mp[1] = -1.0f;
+  };
   if (WH) {
-    // every wave owns its own head: its partial goes straight to the workspace
+    // every wave owns its own head: its partial goes straight to the workspace (or, alone on the row, to `out`)
 #pragma unroll
     for (int mt = 0; mt < MTQ; ++mt) {
       if (!row_ok[mt]) continue;
       const int rr = row0 + mt * 16 + c16;
       const int pos = rr / G, gq = rr - pos * G;
       const int64_t grow = static_cast<int64_t>(q0 + pos) * Hq + h * G + gq;
+      if (P.direct) {
+        const float l = l_run[mt];   // already summed over the row's lanes by softmax_tile
+        store_final(mt, o_acc[mt], l > 0.0f ? out_scale / l : 0.0f, q0 + pos, h * G + gq);
+        if (g == 0 && P.mark_final) mark_row_final(grow);
+        continue;
+      }
       float* op = P.ws_o + (static_cast<int64_t>(by) * P.total_rows + grow) * kD + 4 * g;
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt)
@@ -529,12 +567,12 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
     }
     return;
   }
-  // ---- merge the four waves of the workgroup (they hold disjoint token ranges of the same rows) ------
-  // through LDS, so one partial per workgroup and row goes to the workspace instead of four
+  // ---- merge the R waves of each head (they hold disjoint token ranges of the same rows) through LDS, so one
+  // partial per workgroup and row goes to the workspace instead of R — or, in direct mode, the finished row to `out`
   __syncthreads();  // every wave is done with its V tile: the LDS is free
-  float* xm = reinterpret_cast<float*>(v_lds_raw);  // [4 waves][MTQ][16 rows] running max
-  float* xl = xm + 4 * MTQ * 16;                         // [4][MTQ][16] running sum
-  float* xo = xl + 4 * MTQ * 16;                         // [3 waves][MTQ][16 rows][128] rescaled O of waves 1..3
+  float* xm = reinterpret_cast<float*>(v_lds_raw);  // [NW waves][MTQ][16 rows] running max
+  float* xl = xm + NW * MTQ * 16;                   // [NW][MTQ][16] running sum
+  float* xo = xl + NW * MTQ * 16;                   // [NW - HPW non-leader waves][MTQ][16 rows][128] rescaled O
 #pragma unroll
   for (int mt = 0; mt < MTQ; ++mt)
     if (g == 0) {
@@ -542,13 +580,14 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
       xl[(wave * MTQ + mt) * 16 + c16] = l_run[mt];
     }
   __syncthreads();
+  const int w0 = head_local * R;   // first wave of this head's group
   float scale_w[MTQ], m_all[MTQ], l_all[MTQ];
 #pragma unroll
   for (int mt = 0; mt < MTQ; ++mt) {
     float M = -INFINITY;
-    for (int w = 0; w < 4; ++w) M = fmaxf(M, xm[(w * MTQ + mt) * 16 + c16]);
+    for (int w = w0; w < w0 + R; ++w) M = fmaxf(M, xm[(w * MTQ + mt) * 16 + c16]);
     float L = 0.0f;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = w0; w < w0 + R; ++w) {
       const float mw = xm[(w * MTQ + mt) * 16 + c16];
       if (mw > -INFINITY) L += xl[(w * MTQ + mt) * 16 + c16] * __builtin_amdgcn_exp2f(mw - M);
     }
@@ -556,39 +595,49 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
     l_all[mt] = L;
     scale_w[mt] = (m_run[mt] > -INFINITY ? __builtin_amdgcn_exp2f(m_run[mt] - M) : 0.0f) * out_scale;
   }
-  if (wave > 0) {
+  const int nl = head_local * (R - 1) + (range - 1);   // slot of a non-leader wave in xo
+  if (range > 0) {
 #pragma unroll
     for (int mt = 0; mt < MTQ; ++mt)
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt) {
-        float* dst = xo + ((static_cast<size_t>(wave - 1) * MTQ + mt) * 16 + c16) * kD + dt * 16 + 4 * g;
+        float* dst = xo + ((static_cast<size_t>(nl) * MTQ + mt) * 16 + c16) * kD + dt * 16 + 4 * g;
         *reinterpret_cast<float4*>(dst) = make_float4(o_acc[mt][dt][0] * scale_w[mt], o_acc[mt][dt][1] * scale_w[mt],
                                                        o_acc[mt][dt][2] * scale_w[mt], o_acc[mt][dt][3] * scale_w[mt]);
       }
   }
   __syncthreads();
-  if (wave != 0) return;
-  const int bpart = by;  // one partial per workgroup
+  if (range != 0) return;
+  const int bpart = by;  // one partial per workgroup and head
 #pragma unroll
   for (int mt = 0; mt < MTQ; ++mt) {
     if (!row_ok[mt]) continue;
     const int rr = row0 + mt * 16 + c16;
     const int pos = rr / G, gq = rr - pos * G;
     const int64_t grow = static_cast<int64_t>(q0 + pos) * Hq + h * G + gq;
-    float* op = P.ws_o + (static_cast<int64_t>(bpart) * P.total_rows + grow) * kD + 4 * g;
+    f32x4 acc[8];
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) {
-      float4 acc = make_float4(o_acc[mt][dt][0] * scale_w[mt], o_acc[mt][dt][1] * scale_w[mt],
-                               o_acc[mt][dt][2] * scale_w[mt], o_acc[mt][dt][3] * scale_w[mt]);
-      for (int w = 0; w < 3; ++w) {
-        const float4 o = *reinterpret_cast<const float4*>(xo + ((static_cast<size_t>(w) * MTQ + mt) * 16 + c16) * kD + dt * 16 + 4 * g);
-        acc.x += o.x;
-        acc.y += o.y;
-        acc.z += o.z;
-        acc.w += o.w;
+      acc[dt] = f32x4{o_acc[mt][dt][0] * scale_w[mt], o_acc[mt][dt][1] * scale_w[mt], o_acc[mt][dt][2] * scale_w[mt],
+                      o_acc[mt][dt][3] * scale_w[mt]};
+      for (int w = 0; w < R - 1; ++w) {
+        const float4 o = *reinterpret_cast<const float4*>(
+            xo + ((static_cast<size_t>(head_local * (R - 1) + w) * MTQ + mt) * 16 + c16) * kD + dt * 16 + 4 * g);
+        acc[dt][0] += o.x;
+        acc[dt][1] += o.y;
+        acc[dt][2] += o.z;
+        acc[dt][3] += o.w;
       }
-      *reinterpret_cast<float4*>(op + dt * 16) = acc;
     }
+    if (P.direct) {
+      store_final(mt, acc, l_all[mt] > 0.0f ? 1.0f / l_all[mt] : 0.0f, q0 + pos, h * G + gq);   // out_scale is in scale_w
+      if (g == 0 && P.mark_final) mark_row_final(grow);
+      continue;
+    }
+    float* op = P.ws_o + (static_cast<int64_t>(bpart) * P.total_rows + grow) * kD + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+      *reinterpret_cast<float4*>(op + dt * 16) = make_float4(acc[dt][0], acc[dt][1], acc[dt][2], acc[dt][3]);
     if (g == 0) {
       float* mp = P.ws_ml + (static_cast<int64_t>(bpart) * P.total_rows + grow) * 2;
       mp[0] = m_all[mt] * kLn2;
@@ -598,10 +647,10 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
   }
 }
 
-template <int MTQ, bool WH, bool KV8, int NW = 4>
+template <int MTQ, int HPW, bool KV8, int NW = 4>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((MTQ == 1 && NW == 4) ? 3 : 2, (MTQ == 1 && NW == 4) ? 3 : 2))) verify_attn_kernel(AttnParams P) {
   __shared__ uint4 v_lds_raw[ShortLds<MTQ, NW>::kU4];
-  verify_attn_body<MTQ, WH, KV8, NW>(P, v_lds_raw, blockIdx.x, blockIdx.y);
+  verify_attn_body<MTQ, HPW, KV8, NW>(P, v_lds_raw, blockIdx.x, blockIdx.y);
 }
 
 // One 32-token KV tile (K and V images in LDS at kb / vb, v_tile_off layout) against the NT row tiles of a wave
@@ -971,7 +1020,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 // workgroups still sit beside the short ones on the CUs (both bodies are 4 waves, <= 256 VGPRs, 64 KiB LDS: two
 // workgroups per CU), and they come first in the grid so that they are placed before the CUs fill up.
 // The long part is padded to a multiple of 8 workgroups (idle ones), which keeps the short body's XCD-aware item mapping.
-template <bool WH, bool KV8, int MTQ>
+template <int HPW, bool KV8, int MTQ>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 verify_attn_pair_kernel(AttnParams PS, AttnParams PL, int n_long_wg, int n_long_pad, int long_x, int long_y, int short_x) {
   __shared__ uint4 lds[kLong4LdsU4 > ShortLds<MTQ, 4>::kU4 ? kLong4LdsU4 : ShortLds<MTQ, 4>::kU4];
@@ -987,7 +1036,7 @@ verify_attn_pair_kernel(AttnParams PS, AttnParams PL, int n_long_wg, int n_long_
   } else {
     const int sb = b - n_long_pad;
     __builtin_amdgcn_s_setprio(3);   // the memory-bound short body sets the launch's end: its waves issue first
-    verify_attn_body<MTQ, WH, KV8, 4>(PS, lds, sb % short_x, sb / short_x);
+    verify_attn_body<MTQ, HPW, KV8, 4>(PS, lds, sb % short_x, sb / short_x);
   }
   if (PS.trace) {
     __syncthreads();
@@ -1021,6 +1070,8 @@ verify_attn_combine_kernel(const float* __restrict__ ws_o, const float* __restri
     m_l = ml.x;
     l_l = ml.y;
   }
+  // slot 0 with l < 0: the attention launch already wrote this row's finished value (direct mode); leave it alone
+  if (__shfl(l_l, 0) < 0.0f) return;
   float M = m_l;
   for (int off = 32; off > 0; off >>= 1) M = fmaxf(M, __shfl_xor(M, off));
   const float w_l = m_l == -INFINITY ? 0.0f : __expf(m_l - M);
@@ -1137,6 +1188,30 @@ using namespace aic;
 
 static int64_t* g_attn_trace = nullptr;
 static int g_attn_trace_cap = 0;
+static int g_force_hpw = 0, g_force_splits = 0;   // aic_debug_attn_layout (tools/microbench.py sweeps); 0 = choose
+
+// Layout of the short body for a call whose query lengths the host knows: kv heads per workgroup (4, 2 or 1: the four
+// waves are HPW head groups of R = 4 / HPW token ranges each, merged through LDS) and cross-workgroup token splits.
+// One split means no partials at all: the workgroup that saw a row's whole context writes the finished row ("direct"),
+// and a call without long drafts needs no combine launch.
+// MEASURED (tools/microbench.py layout, profiles/r02_microbench.txt; 4224-token contexts, per call incl. combine):
+//   64 requests: HPW 4 x 2 splits 172 us | HPW 2 x 1 split (direct, no combine) 179 us | HPW 1 x 1 split 202 us
+//   32 requests: HPW 4 x 4 splits  91 us | HPW 2 x 2 splits 96 us | HPW 1 x 1 split (direct) 104 us | HPW 2 x 1 143 us
+//   16 requests: HPW 4 x 8 splits  51 us | HPW 2 x 4 splits 53 us | HPW 1 x 2 splits 58 us
+// i.e. what a workgroup reads per token (HPW x 256 contiguous bytes: DRAM page locality) outweighs the partial write and
+// the combine launch that cross-workgroup splits cost.  So: as many heads per workgroup as divide the head count, splits
+// by pick_splits, and the direct form whenever that leaves a single split (many requests, or few heads per rank).
+struct ShortLayout {
+  int hpw, splits;
+};
+static ShortLayout pick_short_layout(int n_req, int num_kv_heads, int max_seq_len, int max_wgs) {
+  int hpw = num_kv_heads % 4 == 0 ? 4 : (num_kv_heads % 2 == 0 ? 2 : 1);
+  if (g_force_hpw && num_kv_heads % g_force_hpw == 0) hpw = g_force_hpw;
+  const int R = 4 / hpw;
+  int splits = pick_splits(n_req * (num_kv_heads / hpw), max_seq_len, 2 * R, 1, max_wgs);
+  if (g_force_splits) splits = g_force_splits;
+  return ShortLayout{hpw, splits};
+}
 
 extern "C" {
 
@@ -1145,6 +1220,14 @@ extern "C" {
 int aic_debug_attn_trace(int64_t* buf, int capacity_wgs) {
   g_attn_trace = buf;
   g_attn_trace_cap = capacity_wgs;
+  return AIC_OK;
+}
+
+// debug: force the short body's heads per workgroup (4 / 2 / 1) and / or split count for host-partitioned calls
+// (0 = let pick_short_layout choose); every setting computes the same result
+int aic_debug_attn_layout(int heads_per_wg, int splits) {
+  g_force_hpw = heads_per_wg;
+  g_force_splits = splits;
   return AIC_OK;
 }
 
@@ -1250,8 +1333,17 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   // rocprofv3 on the bench, 50 short requests otherwise took 5 splits = 500 workgroups, left no room for the long part,
   // and the call fell back to two launches whose long kernel alone ran 212 us
   const bool mixed = split_lists && n_short > 0 && n_long > 0;
-  int n_splits = pick_splits((split_lists ? std::max(n_short, 1) : batch) * hgroups, max_seq_len, wave_heads ? 2 : 8, 1,
-                             mixed ? cu_count() : 0);
+  int hpw = wave_heads ? 4 : 1;   // the generic launch (lengths unknown on the host) keeps r01's two forms
+  int n_splits;
+  if (split_lists && n_short > 0) {
+    const ShortLayout lay = pick_short_layout(n_short, num_kv_heads, max_seq_len, mixed ? cu_count() : 0);
+    hpw = lay.hpw;
+    n_splits = lay.splits;
+  } else {
+    n_splits = pick_splits(batch * hgroups, max_seq_len, wave_heads ? 2 : 8, 1, 0);
+  }
+  const int hgroups_s = num_kv_heads / hpw;              // head groups of the short launch
+  const bool direct = split_lists && n_short > 0 && n_splits == 1;
   int n_splits_long = (split_lists && n_long > 0) ? pick_splits(n_long * num_kv_heads, max_seq_len, 8, 2) : 0;
   auto fits = [&](int parts) { return static_cast<size_t>(parts) * rows * (kD + 2) * sizeof(float) <= workspace_bytes; };
   while (n_splits > 1 && !fits(n_splits)) --n_splits;
@@ -1283,9 +1375,27 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   P.v_scale = v_scale;
   P.dbg = 0;
   P.trace = nullptr;
+  P.out = static_cast<uint16_t*>(out);
+  P.out_stride = out_stride;
+  P.direct = 0;
+  P.mark_final = 0;
 
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
+  // short / generic kernel for (row tiles, heads per workgroup, cache dtype)
+  auto launch_short = [&](int mtq_, int hpw_, dim3 grid_) {
+#define AIC_SHORT(MTQ_, HPW_)                                                                  \
+  if (kv8)                                                                                     \
+    hipLaunchKernelGGL((verify_attn_kernel<MTQ_, HPW_, true>), grid_, dim3(256), 0, s, P);     \
+  else                                                                                         \
+    hipLaunchKernelGGL((verify_attn_kernel<MTQ_, HPW_, false>), grid_, dim3(256), 0, s, P);
+    if (mtq_ == 1) {
+      if (hpw_ == 4) { AIC_SHORT(1, 4) } else if (hpw_ == 2) { AIC_SHORT(1, 2) } else { AIC_SHORT(1, 1) }
+    } else {
+      if (hpw_ == 4) { AIC_SHORT(2, 4) } else if (hpw_ == 2) { AIC_SHORT(2, 2) } else { AIC_SHORT(2, 1) }
+    }
+#undef AIC_SHORT
+  };
   if (!split_lists) {
     profile_begin(s);
     // query lengths unknown on the host: rows per request in the common case decide the tile shape; long
@@ -1295,20 +1405,7 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
     P.m_groups = (max_rows + mtq * 16 - 1) / (mtq * 16);
     P.n_items = batch * hgroups;
     dim3 grid(static_cast<unsigned>((P.n_items + 7) / 8 * 8 * P.m_groups), n_splits, 1);
-#define AIC_ATTN_LAUNCH(MTQ_, WH_)                                                                   \
-  if (kv8)                                                                                           \
-    hipLaunchKernelGGL((verify_attn_kernel<MTQ_, WH_, true>), grid, dim3(256), 0, s, P);             \
-  else                                                                                               \
-    hipLaunchKernelGGL((verify_attn_kernel<MTQ_, WH_, false>), grid, dim3(256), 0, s, P);
-    if (mtq == 1 && wave_heads) {
-      AIC_ATTN_LAUNCH(1, true)
-    } else if (mtq == 1) {
-      AIC_ATTN_LAUNCH(1, false)
-    } else if (wave_heads) {
-      AIC_ATTN_LAUNCH(2, true)
-    } else {
-      AIC_ATTN_LAUNCH(2, false)
-    }
+    launch_short(mtq, hpw, grid);
     profile_end(s);
   } else {
     // the caller partitioned the batch: `short_reqs` have q_len * G <= 16 * mtq_short rows (one pass of the
@@ -1318,7 +1415,9 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
     SideStream* side = nullptr;
     const int per_block_rows_p = 4 * kLongTilesPerWave * 16;
     const int long_z = (max_rows + per_block_rows_p - 1) / per_block_rows_p;
-    const int short_wg = (n_short * hgroups + 7) / 8 * 8 * n_splits;
+    const int short_wg = (n_short * hgroups_s + 7) / 8 * 8 * n_splits;
+    P.direct = direct ? 1 : 0;
+    P.mark_final = (direct && n_long > 0) ? 1 : 0;
     // one launch for both kinds of request when every workgroup of it can be resident at once (two per CU).  (Letting
     // the long part take the whole chip first — 2 workgroups per CU, the short ones dispatched as those retire — was
     // measured and is worse: 59 short + 5 long 214 us against 206 us, and the bench's real mix 267 us against 182 us.)
@@ -1338,24 +1437,26 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
       PL.n_splits = n_splits_long;
       P.req_list = short_reqs;
       P.m_groups = 1;
-      P.n_items = n_short * hgroups;
+      P.n_items = n_short * hgroups_s;
       const int long_x = n_long * num_kv_heads;
       const int n_long_wg = long_x * n_splits_long * long_z, n_long_pad = (n_long_wg + 7) / 8 * 8;
       const int short_x = (P.n_items + 7) / 8 * 8;
       profile_begin(s);
       const dim3 pgrid(static_cast<unsigned>(n_long_pad + short_wg));
       P.trace = (g_attn_trace && static_cast<int>(pgrid.x) <= g_attn_trace_cap) ? g_attn_trace : nullptr;
-#define AIC_PAIR_LAUNCH(WH_, KV8_)                                                                              \
+#define AIC_PAIR_LAUNCH(HPW_, KV8_)                                                                             \
   if (mtq_short == 1)                                                                                           \
-    hipLaunchKernelGGL((verify_attn_pair_kernel<WH_, KV8_, 1>), pgrid, dim3(256), 0, s, P, PL, n_long_wg, n_long_pad, long_x, \
+    hipLaunchKernelGGL((verify_attn_pair_kernel<HPW_, KV8_, 1>), pgrid, dim3(256), 0, s, P, PL, n_long_wg, n_long_pad, long_x, \
                        n_splits_long, short_x);                                                                 \
   else                                                                                                          \
-    hipLaunchKernelGGL((verify_attn_pair_kernel<WH_, KV8_, 2>), pgrid, dim3(256), 0, s, P, PL, n_long_wg, n_long_pad, long_x, \
+    hipLaunchKernelGGL((verify_attn_pair_kernel<HPW_, KV8_, 2>), pgrid, dim3(256), 0, s, P, PL, n_long_wg, n_long_pad, long_x, \
                        n_splits_long, short_x);
-      if (wave_heads) {
-        if (kv8) { AIC_PAIR_LAUNCH(true, true) } else { AIC_PAIR_LAUNCH(true, false) }
+      if (hpw == 4) {
+        if (kv8) { AIC_PAIR_LAUNCH(4, true) } else { AIC_PAIR_LAUNCH(4, false) }
+      } else if (hpw == 2) {
+        if (kv8) { AIC_PAIR_LAUNCH(2, true) } else { AIC_PAIR_LAUNCH(2, false) }
       } else {
-        if (kv8) { AIC_PAIR_LAUNCH(false, true) } else { AIC_PAIR_LAUNCH(false, false) }
+        if (kv8) { AIC_PAIR_LAUNCH(1, true) } else { AIC_PAIR_LAUNCH(1, false) }
       }
 #undef AIC_PAIR_LAUNCH
       profile_end(s);
@@ -1387,24 +1488,16 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
     if (n_short > 0) {
       P.req_list = short_reqs;
       P.m_groups = 1;
-      P.n_items = n_short * hgroups;
+      P.n_items = n_short * hgroups_s;
       dim3 grid(static_cast<unsigned>((P.n_items + 7) / 8 * 8), n_splits, 1);
-      if (mtq_short == 1 && wave_heads) {
-        AIC_ATTN_LAUNCH(1, true)
-      } else if (mtq_short == 1) {
-        AIC_ATTN_LAUNCH(1, false)
-      } else if (wave_heads) {
-        AIC_ATTN_LAUNCH(2, true)
-      } else {
-        AIC_ATTN_LAUNCH(2, false)
-      }
+      launch_short(mtq_short, hpw, grid);
       profile_end(s);
     }
     if (n_long > 0 && short_first && (rc = launch_long()) != AIC_OK) return rc;
     if (overlap) AIC_HIP_TRY(hipStreamWaitEvent(s, side->join, 0));
   }
-#undef AIC_ATTN_LAUNCH
   if ((rc = launch_status("verify_attn_kernel")) != AIC_OK) return rc;
+  if (P.direct && !P.mark_final) return AIC_OK;   // every row of the call is already final: no combine launch
   hipLaunchKernelGGL(verify_attn_combine_kernel<128>, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s, P.ws_o,
                      P.ws_ml, n_parts_total, static_cast<int>(rows), num_q_heads, static_cast<uint16_t*>(out), out_stride);
   return launch_status("verify_attn_combine_kernel");

@@ -315,6 +315,39 @@ def test_verify_attention_head_size_64(cfg):
         assert torch.allclose(got.float().cpu(), want, atol=1e-3, rtol=2 ** -8), (extra, (got.float().cpu() - want).abs().max())
 
 
+@pytest.mark.parametrize("kv", ["bf16", "fp8"])
+def test_verify_attention_every_short_layout(kv):
+    """The short body's layouts for host-partitioned calls — 4 / 2 / 1 kv heads per workgroup (the waves of a head merge
+    their token ranges through LDS) x 1 / 2 / 3 cross-workgroup splits; one split writes the finished row itself (no
+    partials, no combine launch) — forced through the debug entry point: every one must give the oracle's result, with
+    and without long drafts in the call (rows finished by the attention launch must survive the combine launch)."""
+    from arcticinference_amd import _native as N
+    D, Hq, Hkv, bs = 128, 32, 8, 16
+    cases = [([4, 1, 3, 4, 2, 1], [300, 17, 1025, 64, 2049, 33]),              # all short: direct mode skips the combine
+             ([4, 33, 2, 17, 4, 1], [900, 1300, 64, 2100, 33, 16])]           # mixed: short rows direct, long rows combined
+    ops = _ops()
+    try:
+        for q_lens, ctxs in cases:
+            q, kc, vc, bt, qsl = _attn_case(len(ctxs), Hq, Hkv, D, q_lens, ctxs, bs, seed=17)
+            ks = vs = 1.0
+            kw = {}
+            if kv == "fp8":
+                ks, vs = 0.04, 0.02
+                kc, vc = O.fp8_sat(kc.float() / ks, "e4m3"), O.fp8_sat(vc.float() / vs, "e4m3")
+                kw = dict(k_scale=torch.tensor([ks], device=DEV), v_scale=torch.tensor([vs], device=DEV))
+            want = O.verify_attention(q, kc, vc, bt, ctxs, qsl, D ** -0.5, ks, vs)
+            args = (q.to(DEV), kc.to(DEV), vc.to(DEV), bt.to(DEV), torch.tensor(ctxs, dtype=torch.int32, device=DEV),
+                    torch.tensor(qsl, device=DEV), max(q_lens), max(ctxs), D ** -0.5)
+            for hpw in (4, 2, 1):
+                for splits in (1, 2, 3):
+                    N.lib().aic_debug_attn_layout(hpw, splits)
+                    out = torch.full((sum(q_lens), Hq, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+                    got = ops.verify_attention(*args, out=out, q_lens_host=q_lens, **kw).float().cpu()
+                    assert torch.allclose(got, want, atol=1e-3, rtol=2 ** -8), (kv, q_lens, hpw, splits, (got - want).abs().max())
+    finally:
+        N.lib().aic_debug_attn_layout(0, 0)
+
+
 def test_verify_attention_plan_equals_direct_call():
     """VerifyAttentionPlan (arguments built once, one foreign call per layer) gives the bits of verify_attention()."""
     D, Hq, Hkv = 128, 32, 8

@@ -188,6 +188,22 @@ if __name__ == "__main__":
         attn(B=16, qlen=17, split=True)
         attn(B=5, qlen=33, split=True)
         attn(B=1, qlen=33, split=True)
+    if "layout" in what:     # the short body's layouts (heads per workgroup x cross-workgroup splits), forced one by one
+        for B, combos in ((64, ((0, 0), (4, 2), (2, 1), (2, 2), (1, 1))), (32, ((0, 0), (4, 4), (2, 2), (2, 1), (1, 1), (1, 2))),
+                          (16, ((0, 0), (4, 8), (2, 4), (1, 2), (1, 1)))):
+            for hpw, sp in combos:
+                N.lib().aic_debug_attn_layout(hpw, sp)
+                print(f"layout hpw={hpw} splits={sp}: ", end="")
+                attn_mix(B, 0)
+        for hpw, sp in ((0, 0), (4, 2), (2, 1), (1, 1)):
+            N.lib().aic_debug_attn_layout(hpw, sp)
+            print(f"layout hpw={hpw} splits={sp}: ", end="")
+            attn_mix(59, 5)
+        for hpw in (2, 1):          # two kv heads per rank (an 8-kv-head model under SP = 4)
+            N.lib().aic_debug_attn_layout(hpw, 0)
+            print(f"layout hpw={hpw} splits=auto: ", end="")
+            attn_mix(64, 0, Hq=8, Hkv=2)
+        N.lib().aic_debug_attn_layout(0, 0)
     if "pmc" in what:      # the cases whose kernels tools/pmc_kernels.py tells apart by name (few iterations: counters, not time)
         _t = timeit
         timeit = lambda fn, iters=4, warm=1: _t(fn, iters=4, warm=1)
