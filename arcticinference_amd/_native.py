@@ -79,6 +79,7 @@ _SIGNATURES = {
     "aic_sc_cache_prompts": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int]),
     "aic_sc_evict_prompt": (c_int, [c_void_p, c_int64]),
     "aic_sc_update_response": (c_int, [c_void_p, c_int64, c_void_p, c_int]),
+    "aic_sc_warm": (c_int, [c_void_p, c_int, c_void_p]),
     "aic_sc_update_responses": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "aic_sc_speculate_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -886,6 +886,21 @@ int aic_sc_update_response(aic_suffix_cache* c, int64_t req, const int32_t* toke
   return AIC_OK;
 }
 
+// Pulls the tree state that the next aic_sc_update_responses for these requests will touch first into the CPU cache
+// (read-only; HostTree::warm).  Meant to be called while the caller waits for the GPU anyway.
+int aic_sc_warm(aic_suffix_cache* c, int n_req, const int64_t* reqs) {
+  AIC_REQUIRE(c && n_req >= 0 && (n_req == 0 || reqs), "bad arguments to aic_sc_warm");
+  volatile int64_t sink = 0;
+  for (int r = 0; r < n_req; ++r) {
+    auto it = c->seq_of.find(reqs[r]);
+    if (it != c->seq_of.end()) sink = sink + c->global->host.warm(it->second);
+    auto pt = c->prompts.find(reqs[r]);
+    if (pt != c->prompts.end() && !pt->second->builder.joinable()) sink = sink + pt->second->host.warm(0);
+  }
+  (void)sink;
+  return AIC_OK;
+}
+
 int aic_sc_update_responses(aic_suffix_cache* c, int n_req, const int64_t* reqs, const int32_t* tokens,
                             const int32_t* lens) {
   AIC_REQUIRE(c && n_req >= 0 && (n_req == 0 || (reqs && lens)), "bad arguments to aic_sc_update_responses");

@@ -328,6 +328,25 @@ class HostTree {
   }
   int tok_at(int32_t slot, int32_t pos) const { return seqs_[slot].toks[pos]; }
 
+  // ---- cache warm-up ------------------------------------------------------------------------------
+ public:
+  // Reads (and so pulls into the cache) what the next append() to `seq_id` will look at first: the records of its active
+  // suffixes that are not open leaves and the headers / first buckets of their child maps.  Between two engine steps the
+  // host does ~7 ms of other work and the trees go cold; append() is then a chain of dependent cache misses.  The engine
+  // calls this while it would otherwise only wait for the GPU.  Returns a checksum so the reads cannot be dropped.
+  int64_t warm(int seq_id) const {
+    auto it = slot_of_.find(seq_id);
+    if (it == slot_of_.end()) return 0;
+    int64_t acc = 0;
+    for (int32_t e : seqs_[it->second].active) {
+      if (e < 0) continue;
+      acc += recs_[e].count;
+      const KidMap* km = kids_[e];
+      if (km && !km->empty()) acc += km->begin()->second + static_cast<int64_t>(km->bucket_count());
+    }
+    return acc;
+  }
+
   // ---- open leaves -------------------------------------------------------------------------------
  public:
   // tokens on the edge into node i (an open leaf's edge runs to the current end of its sequence)

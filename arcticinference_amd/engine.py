@@ -387,6 +387,10 @@ class HotPathEngine:
         s, spec, dev = self.shape, self.spec, self.device
         L, live, reqs, B, n_draft, out_pin, rej, lstm_out, use_lstm = (c.lane, c.live, c.reqs, c.B, c.n_draft, c.out_pin, c.rej,
                                                                       c.lstm_out, c.use_lstm)
+        if self.suffix_cache is not None and B <= spec.disable_by_batch_size:
+            # the trees went cold during the step: read what the update will touch while the GPU still works
+            # (after the wait instead, the same reads cost 0.055 ms and buy back no more than that)
+            self.suffix_cache.warm([r.req_id for r in reqs])
         L.out_ev.synchronize()                           # the step's only blocking wait before the proposals
         out_host = out_pin.numpy()
         _mark('wait_gpu_accept')

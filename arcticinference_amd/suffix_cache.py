@@ -209,6 +209,11 @@ class SuffixCache:
             raise ValueError("update_responses: lens do not add up to the token array")
         N.check(N.lib().aic_sc_update_responses(self._h, len(keys), keys.ctypes.data, flat.ctypes.data, lens.ctypes.data))
 
+    def warm(self, req_ids: Sequence[Hashable]) -> None:
+        """Read-only CPU-cache warm-up of the trees of these requests (aic_sc_warm): call while waiting for the GPU."""
+        keys = np.asarray([self._key(r) for r in req_ids], np.int64)
+        N.check(N.lib().aic_sc_warm(self._h, len(keys), keys.ctypes.data))
+
     def speculate(self, req_id: Hashable, pattern: Sequence[int], max_spec_tokens: Optional[int] = None,
                   max_spec_factor: float = 1.0, max_spec_offset: float = 0.0, min_token_prob: float = 0.1,
                   use_tree_spec: bool = False, use_cached_prompt: bool = True) -> SuffixSpecResult:

@@ -129,6 +129,10 @@ int aic_sc_update_response(aic_suffix_cache* c, int64_t req, const int32_t* toke
 int aic_sc_update_responses(aic_suffix_cache* c, int n_req, const int64_t* reqs, const int32_t* tokens /*host, concatenated*/,
                             const int32_t* lens);
 
+/* read-only cache warm-up for the requests' trees (what the next update_responses touches first); call it while waiting for
+ * the GPU: between two engine steps the trees fall out of the CPU cache and the update is a chain of dependent misses */
+int aic_sc_warm(aic_suffix_cache* c, int n_req, const int64_t* reqs /*host*/);
+
 /* speculate for a batch of requests (suffix_cache.py:151-222 applied per request; the call
  * pattern of model_runner.py:680-744).  All arrays are host arrays of length n_query unless
  * noted.  patterns: concatenated int32, pattern_lens[i] tokens each (only the last max_depth of
