@@ -359,23 +359,29 @@ def main():
 
     # N > 1 with shift parallelism: the decode-size steps above ran in shift (TP) mode.  A few extra steps, outside
     # `value`, with shift off put the Ulysses all-to-all path (2 RCCL all_to_all_single per layer) on the record too.
-    a2a_ms = None
+    a2a_ms, a2a_error = None, None
     if ulysses is not None and ulysses.enable_shift_parallel and steps_shift > 0:
-        ulysses.enable_shift_parallel = False
-        k2 = max(4, min(8, args.steps))
-        run_step()
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(k2):
+        # an error here (the same on every rank: the inputs are seeded alike) must not cost the run its JSON line
+        try:
+            ulysses.enable_shift_parallel = False
+            k2 = max(4, min(8, args.steps))
             run_step()
-        barrier()
-        a2a = time.perf_counter() - t1
-        if dist is not None:
-            t = torch.tensor([a2a], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            a2a = float(t.item())
-        a2a_ms = a2a / k2 * 1e3
-        ulysses.enable_shift_parallel = True
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(k2):
+                run_step()
+            barrier()
+            a2a = time.perf_counter() - t1
+            if dist is not None:
+                t = torch.tensor([a2a], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                a2a = float(t.item())
+            a2a_ms = a2a / k2 * 1e3
+        except Exception as e:                      # noqa: BLE001 - reported in the line, never swallowed silently
+            a2a_error = "%s: %s" % (type(e).__name__, e)
+            print("bench: the extra all-to-all steps failed: " + a2a_error, file=sys.stderr, flush=True)
+        finally:
+            ulysses.enable_shift_parallel = True
 
     if rank == 0:
         value = gen_total / elapsed
@@ -439,6 +445,7 @@ def main():
             "tokens_per_s_per_gpu": value / world,
             "steps_in_shift_mode": steps_shift, "steps_in_sp_mode": steps_sp,
             "ulysses_all_to_all_path_ms_per_step": a2a_ms,
+            "ulysses_all_to_all_path_error": a2a_error,
             "mean_accepted_draft_len": st.accepted / max(st.num_drafts, 1),
             "reference_suffix_replay": golden_accept,
             "requests_replaced_in_timed_region": replaced_total,
