@@ -1054,6 +1054,8 @@ verify_attn_pair_kernel(AttnParams PS, AttnParams PL, int n_long_wg, int n_long_
 }
 
 // one wavefront per output row (token, q head): merge the n_parts partials
+// (Merging inside the attention launch instead — tickets, last wave to arrive reads the slots back — was built and
+// measured: no faster for short-only calls, 20-35 us slower with long drafts; profiles/r02_in_launch_merge_experiment.txt.)
 template <int D>
 __global__ void __launch_bounds__(256)
 verify_attn_combine_kernel(const float* __restrict__ ws_o, const float* __restrict__ ws_ml, int n_parts, int total_rows,
