@@ -63,6 +63,11 @@ __host__ __device__ inline float bf16_to_f32(uint16_t h) {
 }
 // round-to-nearest-even, NaN kept quiet (matches torch's float->bfloat16)
 __host__ __device__ inline uint16_t f32_to_bf16(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // gfx950 converts in hardware (v_cvt_pk_bf16_f32, round-to-nearest-even): one instruction where the bit arithmetic
+  // below is eight — the LSTM cell kernel, VALU-bound on its 64 workgroups, rounds ~25 times per element
+  return __builtin_bit_cast(uint16_t, static_cast<__bf16>(f));
+#endif
   union { uint32_t u; float f; } v;
   v.f = f;
   if ((v.u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((v.u >> 16) | 0x0040u);

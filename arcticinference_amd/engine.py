@@ -285,6 +285,8 @@ class HotPathEngine:
         # context after this step's tokens are written: everything sampled so far + the drafts
         ctx = np.fromiter((len(r.tokens) for r in reqs), dtype=np.int32, count=B) + n_draft
         max_q, max_ctx = int(q_len.max()), int(ctx.max())
+        if getattr(self, "qlen_hist", None) is not None:      # diagnostic (bench.py --qlen-hist): query lengths seen
+            self.qlen_hist += np.bincount(q_len, minlength=len(self.qlen_hist))[:len(self.qlen_hist)]
 
         # Two staging copies per step.  (A) what the KV write and the attention launches need — contexts, query offsets,
         # slots, the short / long request lists — goes first, and the 2 x L launches are enqueued right behind it.  (B) what

@@ -55,6 +55,7 @@ def parse_args():
     ap.add_argument("--no-lstm", action="store_true")
     ap.add_argument("--kv-dtype", default="auto", choices=["auto", "fp8"], help="KV cache dtype (auto = bf16, the headline config)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--qlen-hist", action="store_true", help="diagnostic: histogram of per-request query lengths in the timed steps")
     ap.add_argument("--lanes", type=int, default=1,
                     help="1 (default): every request in one engine step per round (host chain and GPU alternate).  2: the "
                          "live requests form two lanes of B/2 whose steps are interleaved — one lane's host chain (tree "
@@ -333,6 +334,8 @@ def main():
     replaced[0] = 0
     eng.stats = type(eng.stats)()
     eng.timeline = {}
+    if args.qlen_hist:
+        eng.qlen_hist = np.zeros(40, dtype=np.int64)
     if ulysses is not None:
         ulysses.steps_sp = ulysses.steps_shift = 0
     attn_bytes[0] = 0.0
@@ -451,6 +454,7 @@ def main():
             "requests_replaced_in_timed_region": replaced_total,
             "draft_model_policy": ("per request (extension)" if spec.draft_model_per_request else
                                    "reference rule: no draft-model proposal in a step where suffix decoding takes a request"),
+            **({"query_len_histogram": {str(i): int(c) for i, c in enumerate(eng.qlen_hist) if c}} if args.qlen_hist else {}),
             "steps_with_draft_model": st.draft_model_steps, "draft_model_launches_dropped": st.draft_model_dropped,
             "draft_acceptance_rate": st.accepted / max(st.drafted, 1),
             "tokens_per_request_step": st.emitted / max(args.steps * B, 1),
