@@ -158,10 +158,13 @@ quant_rowmajor_fp8_kernel(const uint16_t* __restrict__ src, uint8_t* __restrict_
 __global__ void __launch_bounds__(256)
 ln0_kernel(const uint16_t* __restrict__ hidden, const int32_t* __restrict__ hidden_index, int batch, int H, int MT,
            int scale_input, uint4* __restrict__ x_out, uint16_t* __restrict__ cell, int Ds,
-           unsigned int* __restrict__ amax_bits, int n_amax) {
+           unsigned int* __restrict__ amax_bits, int n_amax, const int32_t* __restrict__ last_tokens,
+           int32_t* __restrict__ tokens) {
   __shared__ float sh[16];
   const int m = blockIdx.x;
   if (m == 0 && threadIdx.x < n_amax) amax_bits[threadIdx.x] = 0u;
+  // the whole-draft entry point hands the conditioning tokens over here (a launch of their own cost 4.8 us, rocprofv3)
+  if (m == 0 && last_tokens && threadIdx.x < batch) tokens[threadIdx.x] = last_tokens[threadIdx.x];
   // zero initial cell state (arctic_speculator.py:781-785)
   for (int j = threadIdx.x * 8; j < Ds; j += 256 * 8)
     *reinterpret_cast<uint4*>(cell + static_cast<int64_t>(m) * Ds + j) = make_uint4(0, 0, 0, 0);
@@ -378,68 +381,98 @@ skinny_gemm_kernel(const uint4* __restrict__ W, const uint4* __restrict__ X, int
 // one workgroup per batch row; r() marks every place the reference materialises a bf16 tensor
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
+// The cell is two launches of kCellParts workgroups per batch row, split where the second normalisation needs a sum
+// over the whole row.  One 1024-thread workgroup per row (rounds 1-2) did all of it in one launch on 64 of the 256 CUs and
+// was bound by its own arithmetic there (two erf, three exp and ~25 bf16 roundings per element: 26-33 us per head,
+// rocprofv3); spread over 4 x 64 workgroups the same arithmetic is a few microseconds per launch.
+constexpr int kCellParts = 4;
+
+struct CellArgs {
+  const float* part;   // [n_splits][m_pad][4 Ds] gate projection partials
+  int n_splits, m_pad, batch;
+  const int32_t* tokens;
+  const uint16_t* emb;
+  int vocab_rows;
+  float alpha;
+  int Ds;
+};
+
+__device__ __forceinline__ float cell_sigmoid(float x) { return r(1.0f / (1.0f + expf(-x))); }
+
+// torch.add(states, z, alpha=emb_weight / state_weight) for gate column n (z column j)
+__device__ __forceinline__ float cell_added(const CellArgs& a, int m, const uint16_t* z, int n, int j) {
+  float s = 0.0f;
+  for (int sp = 0; sp < a.n_splits; ++sp) s += a.part[(static_cast<int64_t>(sp) * a.m_pad + m) * (4 * a.Ds) + n];
+  return r(fmaf(a.alpha, bf16_to_f32(z[j]), r(s)));
+}
+
+// phase A, workgroup (row m, part q): new cell state of columns [q Ds/4, (q+1) Ds/4) and their share of its mean square.
+// The first normalisation's row sum is computed by every part for itself (4 Ds partial reads from L2: nothing next to a
+// cross-workgroup step).
 __global__ void __launch_bounds__(1024)
-lstm_cell_kernel(const float* __restrict__ part, int n_splits, int m_pad, int batch, const int32_t* __restrict__ tokens,
-                 const uint16_t* __restrict__ emb, int vocab_rows, float alpha, const uint16_t* __restrict__ cln_w,
-                 const uint16_t* __restrict__ cln_b, const uint16_t* __restrict__ sln_w,
-                 const uint16_t* __restrict__ sln_b, uint16_t* __restrict__ cell, int Ds, int MT,
-                 uint4* __restrict__ h_out, unsigned int* __restrict__ amax_bits) {
-  extern __shared__ float smem[];  // [Ds] staging of the row between the two normalisations
+lstm_cell_a_kernel(CellArgs a, const uint16_t* __restrict__ cln_w, const uint16_t* __restrict__ cln_b,
+                   uint16_t* __restrict__ cell, float* __restrict__ ss2_part) {
   __shared__ float sh[16];
-  const int m = blockIdx.x;
-  if (m >= batch) {
-    for (int k8 = threadIdx.x; k8 < Ds / 8; k8 += blockDim.x) h_out[xunit_bf16(m, k8, MT)] = make_uint4(0, 0, 0, 0);
-    return;
-  }
-  const int N = 4 * Ds;
-  int tok = tokens[m];
-  if (tok < 0 || tok >= vocab_rows) tok = 0;  // never read outside the table
-  const uint16_t* z = emb + static_cast<int64_t>(tok) * Ds;
+  const int m = blockIdx.x, q = blockIdx.y, Ds = a.Ds;
+  if (m >= a.batch) return;
+  int tok = a.tokens[m];
+  if (tok < 0 || tok >= a.vocab_rows) tok = 0;  // never read outside the table
+  const uint16_t* z = a.emb + static_cast<int64_t>(tok) * Ds;
 
-  auto added = [&](int n, int j) -> float {  // torch.add(states, z, alpha=emb_weight / state_weight)
-    float s = 0.0f;
-    for (int sp = 0; sp < n_splits; ++sp) s += part[(static_cast<int64_t>(sp) * m_pad + m) * N + n];
-    return r(fmaf(alpha, bf16_to_f32(z[j]), r(s)));
-  };
-  auto sigmoid = [](float x) -> float { return r(1.0f / (1.0f + expf(-x))); };
-
-  // pass 1: cell candidate pre-activation and its mean square
   float ss = 0.0f;
   for (int j = threadIdx.x; j < Ds; j += blockDim.x) {
-    const float c = added(3 * Ds + j, j);
-    smem[j] = c;
+    const float c = cell_added(a, m, z, 3 * Ds + j, j);
     ss += r(c * c);
   }
   ss = block_sum(ss, sh);
-  float rs = r(rsqrtf(r(r(ss / static_cast<float>(Ds)) + 1e-6f)));
+  const float rs = r(rsqrtf(r(r(ss / static_cast<float>(Ds)) + 1e-6f)));
 
-  // pass 2: gates, new cell state, its mean square
+  const int j0 = q * (Ds / kCellParts), j1 = j0 + Ds / kCellParts;
   float ss2 = 0.0f;
-  for (int j = threadIdx.x; j < Ds; j += blockDim.x) {
-    float y = r(smem[j] * rs);
+  for (int j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+    float y = r(cell_added(a, m, z, 3 * Ds + j, j) * rs);
     y = r(bf16_to_f32(cln_w[j]) * y);
     y = r(y + bf16_to_f32(cln_b[j]));
-    const float cand = r(r(gelu_erf(y)) * sigmoid(added(Ds + j, j)));           // * input gate
-    const float kept = r(bf16_to_f32(cell[static_cast<int64_t>(m) * Ds + j]) * sigmoid(added(j, j)));  // * forget gate
+    const float cand = r(r(gelu_erf(y)) * cell_sigmoid(cell_added(a, m, z, Ds + j, j)));                        // * input gate
+    const float kept = r(bf16_to_f32(cell[static_cast<int64_t>(m) * Ds + j]) * cell_sigmoid(cell_added(a, m, z, j, j)));  // * forget gate
     const float cnew = r(kept + cand);
     cell[static_cast<int64_t>(m) * Ds + j] = f32_to_bf16(cnew);
-    smem[j] = cnew;
     ss2 += r(cnew * cnew);
   }
   ss2 = block_sum(ss2, sh);
-  rs = r(rsqrtf(r(r(ss2 / static_cast<float>(Ds)) + 1e-6f)));
+  if (threadIdx.x == 0) ss2_part[m * kCellParts + q] = ss2;
+}
 
-  // pass 3: state = gelu(state_ln(cell)) * output gate, written fragment-major for the next GEMMs
+// phase B, workgroup (row m, part q): state = gelu(state_ln(cell)) * output gate for its columns, written fragment-major
+// for the next GEMMs; the row's mean square is the sum of the kCellParts shares in part order
+__global__ void __launch_bounds__(256)
+lstm_cell_b_kernel(CellArgs a, const uint16_t* __restrict__ sln_w, const uint16_t* __restrict__ sln_b,
+                   const uint16_t* __restrict__ cell, const float* __restrict__ ss2_part, int MT, uint4* __restrict__ h_out,
+                   unsigned int* __restrict__ amax_bits) {
+  const int m = blockIdx.x, q = blockIdx.y, Ds = a.Ds;
+  const int k0 = q * (Ds / 8 / kCellParts), k1 = k0 + Ds / 8 / kCellParts;
+  if (m >= a.batch) {
+    for (int k8 = k0 + threadIdx.x; k8 < k1; k8 += blockDim.x) h_out[xunit_bf16(m, k8, MT)] = make_uint4(0, 0, 0, 0);
+    return;
+  }
+  int tok = a.tokens[m];
+  if (tok < 0 || tok >= a.vocab_rows) tok = 0;
+  const uint16_t* z = a.emb + static_cast<int64_t>(tok) * Ds;
+  float ss2 = 0.0f;
+  for (int p = 0; p < kCellParts; ++p) ss2 += ss2_part[m * kCellParts + p];
+  const float rs = r(rsqrtf(r(r(ss2 / static_cast<float>(Ds)) + 1e-6f)));
   float amax = 0.0f;
-  for (int k8 = threadIdx.x; k8 < Ds / 8; k8 += blockDim.x) {
+  for (int k8 = k0 + threadIdx.x; k8 < k1; k8 += blockDim.x) {
+    const uint4 c8 = *reinterpret_cast<const uint4*>(cell + static_cast<int64_t>(m) * Ds + k8 * 8);
+    const uint16_t* cv = reinterpret_cast<const uint16_t*>(&c8);
     uint16_t h[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int j = k8 * 8 + e;
-      float y = r(smem[j] * rs);
+      float y = r(bf16_to_f32(cv[e]) * rs);
       y = r(bf16_to_f32(sln_w[j]) * y);
       y = r(y + bf16_to_f32(sln_b[j]));
-      const float st = r(r(gelu_erf(y)) * sigmoid(added(2 * Ds + j, j)));  // * output gate
+      const float st = r(r(gelu_erf(y)) * cell_sigmoid(cell_added(a, m, z, 2 * Ds + j, j)));  // * output gate
       h[e] = f32_to_bf16(st);
       amax = fmaxf(amax, fabsf(st));
     }
@@ -594,6 +627,7 @@ struct aic_lstm {
   uint4 *x0 = nullptr, *h_bf16 = nullptr, *h_fp8 = nullptr;
   uint16_t* cell = nullptr;
   float* part = nullptr;
+  float* ss2_part = nullptr;   // [64][kCellParts] row sums between the two cell launches
   float* best_val = nullptr;
   int32_t* best_idx = nullptr;
   int32_t* tokens = nullptr;
@@ -687,12 +721,14 @@ static int run_head(aic_lstm* m, int head_index, hipStream_t s, int64_t* out_tok
                                m->gate_rowtiles, steps_total, steps_total / splits, m->part, 4 * Ds, nullptr, 1.0f, 0,
                                0, nullptr, nullptr);
     if (rc != AIC_OK) return rc;
-    // 2. cell update
-    hipLaunchKernelGGL(lstm_cell_kernel, dim3(mpad), dim3(1024), Ds * sizeof(float), s, m->part, splits, mpad, B,
-                       m->tokens, static_cast<const uint16_t*>(m->w.forget_emb), 0x7fffffff, m->alpha,
-                       static_cast<const uint16_t*>(m->w.cell_ln_w), static_cast<const uint16_t*>(m->w.cell_ln_b),
+    // 2. cell update (two launches: see kCellParts)
+    CellArgs ca{m->part, splits, mpad, B, m->tokens, static_cast<const uint16_t*>(m->w.forget_emb), 0x7fffffff, m->alpha, Ds};
+    hipLaunchKernelGGL(lstm_cell_a_kernel, dim3(mpad, kCellParts), dim3(1024), 0, s, ca,
+                       static_cast<const uint16_t*>(m->w.cell_ln_w), static_cast<const uint16_t*>(m->w.cell_ln_b), m->cell,
+                       m->ss2_part);
+    hipLaunchKernelGGL(lstm_cell_b_kernel, dim3(mpad, kCellParts), dim3(128), 0, s, ca,
                        static_cast<const uint16_t*>(m->w.state_ln_w), static_cast<const uint16_t*>(m->w.state_ln_b),
-                       m->cell, Ds, mt, m->h_bf16, m->amax + head_index);
+                       static_cast<const uint16_t*>(m->cell), m->ss2_part, mt, m->h_bf16, m->amax + head_index);
     if ((rc = launch_status("lstm_cell_kernel")) != AIC_OK) return rc;
   }
   // 3. LM head + fused arg-max
@@ -777,6 +813,7 @@ int aic_lstm_create(const aic_lstm_config* cfg, const aic_lstm_weights* w, aic_l
   AIC_ALLOC(m->h_fp8, static_cast<size_t>(mpad) * Ds);
   AIC_ALLOC(m->cell, static_cast<size_t>(mpad) * Ds * 2);
   AIC_ALLOC(m->part, static_cast<size_t>(m->gate_splits) * mpad * 4 * Ds * 4);
+  AIC_ALLOC(m->ss2_part, static_cast<size_t>(mpad) * kCellParts * sizeof(float));
   AIC_ALLOC(m->best_val, static_cast<size_t>(m->head_blocks) * mpad * 4);
   AIC_ALLOC(m->best_idx, static_cast<size_t>(m->head_blocks) * mpad * 4);
   AIC_ALLOC(m->tokens, static_cast<size_t>(mpad) * 4);
@@ -908,7 +945,7 @@ int aic_mlp_create(const aic_lstm_config* cfg, const aic_mlp_weights* w, aic_lst
 void aic_lstm_destroy(aic_lstm* m) {
   if (!m) return;
   void* bufs[] = {m->proj0_t, m->proj1_t, m->head_t, m->head8_t, m->x0,   m->h_bf16, m->h_fp8,
-                  m->cell,    m->part,    m->best_val, m->best_idx, m->tokens, m->amax, m->x_scale};
+                  m->cell,    m->part,    m->ss2_part, m->best_val, m->best_idx, m->tokens, m->amax, m->x_scale};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (void* b : m->mlp_owned)
@@ -922,15 +959,20 @@ int aic_mlp_set_embedding_rows(aic_lstm* m, const void* rows) {
   return AIC_OK;
 }
 
-int aic_lstm_begin(aic_lstm* m, const void* hidden, const int32_t* hidden_index, int batch, void* stream) {
+static int lstm_begin(aic_lstm* m, const void* hidden, const int32_t* hidden_index, const int32_t* last_tokens, int batch,
+                      void* stream) {
   AIC_REQUIRE(m && hidden && batch > 0 && batch <= m->cfg.max_batch, "bad arguments to aic_lstm_begin (batch %d)", batch);
   hipStream_t s = static_cast<hipStream_t>(stream);
   m->cur_batch = batch;
   m->cur_mt = pad_mt(batch);
   hipLaunchKernelGGL(ln0_kernel, dim3(m->cur_mt * 16), dim3(256), 0, s, static_cast<const uint16_t*>(hidden),
                      hidden_index, batch, m->cfg.input_hidden_dim, m->cur_mt, m->cfg.scale_input, m->x0, m->cell,
-                     m->cfg.inner_dim, m->amax, 64);
+                     m->cfg.inner_dim, m->amax, 64, last_tokens, m->tokens);
   return launch_status("ln0_kernel");
+}
+
+int aic_lstm_begin(aic_lstm* m, const void* hidden, const int32_t* hidden_index, int batch, void* stream) {
+  return lstm_begin(m, hidden, hidden_index, nullptr, batch, stream);
 }
 
 int aic_lstm_head(aic_lstm* m, int head_index, const int32_t* last_tokens, int batch, int64_t* out_tokens,
@@ -948,11 +990,9 @@ int aic_lstm_propose(aic_lstm* m, const void* hidden, const int32_t* hidden_inde
                      int batch, int num_predict_tokens, int64_t* out_tokens, float* out_vals, void* stream) {
   AIC_REQUIRE(m && hidden && last_tokens && out_tokens, "null argument to aic_lstm_propose");
   AIC_REQUIRE(num_predict_tokens > 0 && num_predict_tokens <= 64, "num_predict_tokens out of range");
-  int rc = aic_lstm_begin(m, hidden, hidden_index, batch, stream);
+  int rc = lstm_begin(m, hidden, hidden_index, last_tokens, batch, stream);
   if (rc != AIC_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(copy_tokens_kernel, dim3(1), dim3(64), 0, s, last_tokens, m->tokens, batch);
-  if ((rc = launch_status("copy_tokens_kernel")) != AIC_OK) return rc;
   for (int h = 0; h < num_predict_tokens; ++h) {
     rc = run_head(m, h, s, out_tokens, num_predict_tokens, h, out_vals);
     if (rc != AIC_OK) return rc;
