@@ -261,13 +261,15 @@ __device__ __forceinline__ bf16x8 fp8x8_to_bf16x8(uint32_t lo, uint32_t hi) {
                                  2, 3, 4, 5, 6, 7);
 }
 
-// Rows written by a launch with fewer splits than the call's slot count mark their unused slots empty, so the
-// combine kernel can read a fixed number of slots per row (8 bytes per skipped slot).
+// Rows written by a launch with fewer splits than the call's slot count end their slot list with a sentinel
+// {-inf, -2} in the first unused slot: the combine kernel stops there.  (Marking every unused slot empty — 14 scattered
+// 8-byte writes per row when one long draft took 16 splits beside 2-split short rows — made the combine launch of such
+// calls 14 us instead of 5: tools/microbench.py ql, 63 short + 1 long 197 us per call against 190 us for 59 + 5.)
 __device__ __forceinline__ void mark_unused_parts(const AttnParams& P, int64_t grow) {
-  for (int p = P.n_splits; p < P.n_parts_total; ++p) {
-    float* mp = P.ws_ml + (static_cast<int64_t>(p) * P.total_rows + grow) * 2;
+  if (P.n_splits < P.n_parts_total) {
+    float* mp = P.ws_ml + (static_cast<int64_t>(P.n_splits) * P.total_rows + grow) * 2;
     mp[0] = -INFINITY;
-    mp[1] = 0.0f;
+    mp[1] = -2.0f;
   }
 }
 
@@ -647,10 +649,31 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
   }
 }
 
+// Host-partitioned calls (m_groups == 1): the short list holds requests of up to 32 query rows, and every workgroup
+// takes the one- or the two-row-tile form of the body by the rows of ITS request.  Most requests of a step have no draft
+// or a k = 3 draft (<= 16 rows with Hq/Hkv <= 4); suffix drafts of 4-7 tokens (17-32 rows; 46 % of all suffix drafts in
+// the r02 bench, `bench.py --qlen-hist`) used to go through the shared-tile long-draft body, where a request costs ~6 us
+// per layer whatever its length, against ~2.7 us for a workgroup of this streaming body.
+template <int HPW, bool KV8, int NW>
+__device__ __forceinline__ void verify_attn_body_dual(const AttnParams& P, uint4* v_lds_raw, const int bx, const int by) {
+  if (bx >= P.n_items) return;             // m_groups == 1: item == bx
+  const int ridx = bx / (P.num_kv_heads / HPW);
+  const int req = __builtin_amdgcn_readfirstlane(P.req_list ? P.req_list[ridx] : ridx);
+  const int q_len = __builtin_amdgcn_readfirstlane(P.query_start_loc[req + 1] - P.query_start_loc[req]);
+  if (q_len * (P.num_q_heads / P.num_kv_heads) <= 16)
+    verify_attn_body<1, HPW, KV8, NW>(P, v_lds_raw, bx, by);
+  else
+    verify_attn_body<2, HPW, KV8, NW>(P, v_lds_raw, bx, by);
+}
+
+// MTQ = 0: the per-workgroup choice above
 template <int MTQ, int HPW, bool KV8, int NW = 4>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((MTQ == 1 && NW == 4) ? 3 : 2, (MTQ == 1 && NW == 4) ? 3 : 2))) verify_attn_kernel(AttnParams P) {
-  __shared__ uint4 v_lds_raw[ShortLds<MTQ, NW>::kU4];
-  verify_attn_body<MTQ, HPW, KV8, NW>(P, v_lds_raw, blockIdx.x, blockIdx.y);
+  __shared__ uint4 v_lds_raw[ShortLds<MTQ == 0 ? 2 : MTQ, NW>::kU4];
+  if constexpr (MTQ == 0)
+    verify_attn_body_dual<HPW, KV8, NW>(P, v_lds_raw, blockIdx.x, blockIdx.y);
+  else
+    verify_attn_body<MTQ, HPW, KV8, NW>(P, v_lds_raw, blockIdx.x, blockIdx.y);
 }
 
 // One 32-token KV tile (K and V images in LDS at kb / vb, v_tile_off layout) against the NT row tiles of a wave
@@ -1023,7 +1046,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 template <int HPW, bool KV8, int MTQ>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 verify_attn_pair_kernel(AttnParams PS, AttnParams PL, int n_long_wg, int n_long_pad, int long_x, int long_y, int short_x) {
-  __shared__ uint4 lds[kLong4LdsU4 > ShortLds<MTQ, 4>::kU4 ? kLong4LdsU4 : ShortLds<MTQ, 4>::kU4];
+  constexpr int kShortU4 = ShortLds<MTQ == 0 ? 2 : MTQ, 4>::kU4;
+  __shared__ uint4 lds[kLong4LdsU4 > kShortU4 ? kLong4LdsU4 : kShortU4];
   const int b = blockIdx.x;
   int64_t t0 = 0;
   if (PS.trace) t0 = static_cast<int64_t>(__builtin_amdgcn_s_memrealtime());
@@ -1036,7 +1060,10 @@ verify_attn_pair_kernel(AttnParams PS, AttnParams PL, int n_long_wg, int n_long_
   } else {
     const int sb = b - n_long_pad;
     __builtin_amdgcn_s_setprio(3);   // the memory-bound short body sets the launch's end: its waves issue first
-    verify_attn_body<MTQ, HPW, KV8, 4>(PS, lds, sb % short_x, sb / short_x);
+    if constexpr (MTQ == 0)
+      verify_attn_body_dual<HPW, KV8, 4>(PS, lds, sb % short_x, sb / short_x);
+    else
+      verify_attn_body<MTQ, HPW, KV8, 4>(PS, lds, sb % short_x, sb / short_x);
   }
   if (PS.trace) {
     __syncthreads();
@@ -1072,8 +1099,17 @@ verify_attn_combine_kernel(const float* __restrict__ ws_o, const float* __restri
     m_l = ml.x;
     l_l = ml.y;
   }
-  // slot 0 with l < 0: the attention launch already wrote this row's finished value (direct mode); leave it alone
-  if (__shfl(l_l, 0) < 0.0f) return;
+  // slot 0 with l = -1: the attention launch already wrote this row's finished value (direct mode); leave it alone
+  if (__shfl(l_l, 0) == -1.0f) return;
+  // a sentinel (l = -2) ends the row's slot list early (mark_unused_parts); what lies behind it is stale
+  const unsigned long long stop = __ballot(l_l == -2.0f);
+  if (stop) {
+    const int n_row = __ffsll(stop) - 1;
+    if (lane >= n_row) {
+      m_l = -INFINITY;
+      l_l = 0.0f;
+    }
+  }
   float M = m_l;
   for (int off = 32; off > 0; off >>= 1) M = fmaxf(M, __shfl_xor(M, off));
   const float w_l = m_l == -INFINITY ? 0.0f : __expf(m_l - M);
@@ -1347,6 +1383,9 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   const int hgroups_s = num_kv_heads / hpw;              // head groups of the short launch
   const bool direct = split_lists && n_short > 0 && n_splits == 1;
   int n_splits_long = (split_lists && n_long > 0) ? pick_splits(n_long * num_kv_heads, max_seq_len, 8, 2) : 0;
+  // the long part of a mixed call is off the launch's critical path (its workgroups start first and finish at a third
+  // of the launch: per-workgroup trace, 62 short + 2 long); more than 8 token splits only lengthen every row's slot list
+  if (mixed) n_splits_long = std::min(n_splits_long, 8);
   auto fits = [&](int parts) { return static_cast<size_t>(parts) * rows * (kD + 2) * sizeof(float) <= workspace_bytes; };
   while (n_splits > 1 && !fits(n_splits)) --n_splits;
   while (n_splits_long > 1 && !fits(n_splits_long)) --n_splits_long;
@@ -1391,7 +1430,9 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
     hipLaunchKernelGGL((verify_attn_kernel<MTQ_, HPW_, true>), grid_, dim3(256), 0, s, P);     \
   else                                                                                         \
     hipLaunchKernelGGL((verify_attn_kernel<MTQ_, HPW_, false>), grid_, dim3(256), 0, s, P);
-    if (mtq_ == 1) {
+    if (mtq_ == 0) {
+      if (hpw_ == 4) { AIC_SHORT(0, 4) } else if (hpw_ == 2) { AIC_SHORT(0, 2) } else { AIC_SHORT(0, 1) }
+    } else if (mtq_ == 1) {
       if (hpw_ == 4) { AIC_SHORT(1, 4) } else if (hpw_ == 2) { AIC_SHORT(1, 2) } else { AIC_SHORT(1, 1) }
     } else {
       if (hpw_ == 4) { AIC_SHORT(2, 4) } else if (hpw_ == 2) { AIC_SHORT(2, 2) } else { AIC_SHORT(2, 1) }
@@ -1410,10 +1451,10 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
     launch_short(mtq, hpw, grid);
     profile_end(s);
   } else {
-    // the caller partitioned the batch: `short_reqs` have q_len * G <= 16 * mtq_short rows (one pass of the
-    // short body: one MFMA row tile when a k = 3 draft fits it, G <= 4, else two), `long_reqs` go through the
-    // shared-tile body that reads their KV once for up to 192 rows
-    const int mtq_short = 4 * G <= 16 ? 1 : 2;
+    // the caller partitioned the batch: `short_reqs` have q_len * G <= 32 rows (one pass of the short body, one or
+    // two MFMA row tiles chosen per workgroup: verify_attn_body_dual), `long_reqs` go through the shared-tile body
+    // that reads their KV once for up to 192 rows
+    const int mtq_short = 0;
     SideStream* side = nullptr;
     const int per_block_rows_p = 4 * kLongTilesPerWave * 16;
     const int long_z = (max_rows + per_block_rows_p - 1) / per_block_rows_p;
@@ -1447,12 +1488,8 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
       const dim3 pgrid(static_cast<unsigned>(n_long_pad + short_wg));
       P.trace = (g_attn_trace && static_cast<int>(pgrid.x) <= g_attn_trace_cap) ? g_attn_trace : nullptr;
 #define AIC_PAIR_LAUNCH(HPW_, KV8_)                                                                             \
-  if (mtq_short == 1)                                                                                           \
-    hipLaunchKernelGGL((verify_attn_pair_kernel<HPW_, KV8_, 1>), pgrid, dim3(256), 0, s, P, PL, n_long_wg, n_long_pad, long_x, \
-                       n_splits_long, short_x);                                                                 \
-  else                                                                                                          \
-    hipLaunchKernelGGL((verify_attn_pair_kernel<HPW_, KV8_, 2>), pgrid, dim3(256), 0, s, P, PL, n_long_wg, n_long_pad, long_x, \
-                       n_splits_long, short_x);
+  hipLaunchKernelGGL((verify_attn_pair_kernel<HPW_, KV8_, 0>), pgrid, dim3(256), 0, s, P, PL, n_long_wg, n_long_pad, long_x, \
+                     n_splits_long, short_x);
       if (hpw == 4) {
         if (kv8) { AIC_PAIR_LAUNCH(4, true) } else { AIC_PAIR_LAUNCH(4, false) }
       } else if (hpw == 2) {

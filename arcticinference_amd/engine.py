@@ -295,8 +295,7 @@ class HotPathEngine:
         # suffix kernels of one step and the staging copy of the next; building B first was a third of it).
         slot_map = self._slot_mapping(live, reqs, q_len, qsl, T)
         G = self.hq_local // self.hkv_local
-        so = ops.split_order(q_len, G)            # short / long request lists of the attention call
-        order = so[0] if so is not None else np.zeros(0, np.int32)
+        order, n_short_reqs = ops.split_order(q_len, G)            # short / long request lists of the attention call
         stA = self._stage(L, "A", [(ctx, np.int32), (qsl, np.int32), (np.asarray(live), np.int64), (slot_map, np.int64),
                                 (order, np.int32)])
         d_seq, d_qsl, slots, d_slots, order_dev = stA
@@ -305,9 +304,7 @@ class HotPathEngine:
         # (a) KV of the step's tokens for every layer in one launch (A16), then (b) verify attention per layer
         self._write_kv(d_slots, T)
         _mark('host_prepare')
-        self._req_split = None
-        if so is not None:
-            self._req_split = (order_dev[:so[1]], so[1], order_dev[so[1]:], len(so[0]) - so[1])
+        self._req_split = (order_dev[:n_short_reqs], n_short_reqs, order_dev[n_short_reqs:], B - n_short_reqs)
         self._stream = int(torch.cuda.current_stream().cuda_stream)   # looked up once per step, not once per layer
         self._attention_layers(T, bt, d_seq, d_qsl, max_q, max_ctx)
         self.last_ctx_sum = int(ctx.sum())

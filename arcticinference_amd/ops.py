@@ -257,29 +257,27 @@ class VerifyAttentionPlan:
 
 
 def split_order(q_lens_host: Sequence[int], group_size: int):
-    """Host half of split_requests: (request ids with the short ones first, as int32; number of short requests), or
-    None when every request is short (q_len * Hq/Hkv <= 16 rows, or <= 32 rows when Hq/Hkv > 4)."""
+    """Host half of split_requests: (request ids with the short ones first, as int32; number of short requests).
+    Short = q_len * Hq/Hkv <= 32 query rows.  A batch of short requests only still gets its (identity) list: the
+    partitioned call is what lets every workgroup take the one- or two-row-tile form by its own request's rows, where
+    the call without lists has to size every request for the longest."""
     import numpy as np
     ql = np.asarray(q_lens_host)
-    # the short body runs one 16-row MFMA tile per request when a k = 3 draft (4 positions) fits it (G <= 4),
-    # else two (G <= 8): same rule as aic_verify_attention_ex
-    short_rows = 16 if 4 * group_size <= 16 else 32
-    is_short = ql * group_size <= short_rows
-    if is_short.all():
-        return None
+    # same rule as aic_verify_attention_ex
+    is_short = ql * group_size <= 32
+    n_short = int(is_short.sum())
+    if n_short == len(ql):
+        return np.arange(len(ql), dtype=np.int32), n_short
     order = np.concatenate([np.nonzero(is_short)[0], np.nonzero(~is_short)[0]]).astype(np.int32)
-    return order, int(is_short.sum())
+    return order, n_short
 
 
 def split_requests(q_lens_host: Sequence[int], group_size: int, device, order_dev: Optional[torch.Tensor] = None):
     """Partition a batch by query length for aic_verify_attention_ex: (short_ids, n_short, long_ids, n_long) with
-    device int32 id lists, or None when every request is short.  Build it once per engine step and pass it to every
-    layer's verify_attention call.  `order_dev`: the id list already on the device (a caller that stages all of a
-    step's index arrays in one copy passes split_order()'s array through that copy)."""
-    so = split_order(q_lens_host, group_size)
-    if so is None:
-        return None
-    order, n_short = so
+    device int32 id lists.  Build it once per engine step and pass it to every layer's verify_attention call.
+    `order_dev`: the id list already on the device (a caller that stages all of a step's index arrays in one copy
+    passes split_order()'s array through that copy)."""
+    order, n_short = split_order(q_lens_host, group_size)
     lists = order_dev if order_dev is not None else torch.from_numpy(order).to(device, non_blocking=True)
     return lists[:n_short], n_short, lists[n_short:], len(order) - n_short
 

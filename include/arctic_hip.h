@@ -325,8 +325,9 @@ int aic_verify_attention(const void* q, int64_t q_stride, const void* k_cache, c
                          void* out, int64_t out_stride, void* workspace, size_t workspace_bytes,
                          int max_seq_len, void* stream);
 /* Same, for callers that know the query lengths on the host (vLLM keeps num_scheduled_tokens there):
- * the batch is partitioned into `short_reqs` (device int32[n_short], requests with q_len * Hq/Hkv <= 16
- * query rows, or <= 32 rows when Hq/Hkv > 4: one pass of the short body, KV streamed once) and `long_reqs` (device int32[n_long], e.g. 33-token suffix
+ * the batch is partitioned into `short_reqs` (device int32[n_short], requests with q_len * Hq/Hkv <= 32
+ * query rows: one pass of the short body, one or two MFMA row tiles per workgroup by its request's rows, KV streamed
+ * once) and `long_reqs` (device int32[n_long], e.g. 33-token suffix
  * drafts: a shared-tile body reads their KV once for up to 192 rows instead of once per 16-row group).
  * Both kinds run in ONE launch per call whenever all of its workgroups fit on the chip at once (<= 512;
  * otherwise two launches, the long one on a side stream).  max_q_len bounds the long requests.

@@ -324,7 +324,10 @@ def test_verify_attention_every_short_layout(kv):
     from arcticinference_amd import _native as N
     D, Hq, Hkv, bs = 128, 32, 8, 16
     cases = [([4, 1, 3, 4, 2, 1], [300, 17, 1025, 64, 2049, 33]),              # all short: direct mode skips the combine
-             ([4, 33, 2, 17, 4, 1], [900, 1300, 64, 2100, 33, 16])]           # mixed: short rows direct, long rows combined
+             ([4, 33, 2, 17, 4, 1], [900, 1300, 64, 2100, 33, 16]),           # mixed: short rows direct, long rows combined
+             # 17-32 query rows (q_len 5-8 at Hq/Hkv = 4): the two-row-tile form of the short body, chosen per workgroup
+             ([8, 1, 5, 4, 7, 6], [300, 17, 1025, 64, 2049, 33]),
+             ([8, 33, 5, 9, 4, 1, 6], [900, 1300, 64, 2100, 33, 16, 700])]
     ops = _ops()
     try:
         for q_lens, ctxs in cases:

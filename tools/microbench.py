@@ -84,7 +84,7 @@ def attn_mix(n_short=59, n_long=5, q_short=1, q_long=33, ctx=4224, Hq=32, Hkv=8,
     seq = torch.full((B,), ctx, dtype=torch.int32, device=dev)
     qsl = torch.tensor(np.concatenate([[0], np.cumsum(ql)]).astype(np.int32), device=dev)
     out = torch.empty_like(q)
-    rs = ops.split_requests(ql, Hq // Hkv, dev) if n_long else (torch.arange(B, dtype=torch.int32, device=dev), B, None, 0)
+    rs = ops.split_requests(ql, Hq // Hkv, dev)
     i = [0]
 
     def f():
@@ -95,6 +95,32 @@ def attn_mix(n_short=59, n_long=5, q_short=1, q_long=33, ctx=4224, Hq=32, Hkv=8,
     gb = B * ctx * 2 * Hkv * D * (1 if kv8 else 2) / 1e9
     print(f"attn-mix{' fp8kv' if kv8 else ''} short={n_short}x{q_short} long={n_long}x{q_long} ctx={ctx} Hq={Hq} Hkv={Hkv}: {us:8.1f} us  "
           f"{gb / us * 1e6 / 1e3:6.2f} TB/s (incl. combine)")
+
+
+def attn_ql(ql, ctx=4224, Hq=32, Hkv=8, D=128, bs=16, layers=4, jitter=0):
+    """One host-partitioned call over an arbitrary list of query lengths (contexts ctx - jitter .. ctx)."""
+    B = len(ql)
+    nblk = (ctx + bs - 1) // bs
+    nb = B * nblk
+    kvs = [torch.randn(2, nb, bs, Hkv, D, device=dev, dtype=torch.bfloat16) for _ in range(layers)]
+    bt = torch.randperm(nb, device=dev).to(torch.int32).view(B, nblk)
+    q = torch.randn(sum(ql), Hq, D, device=dev, dtype=torch.bfloat16)
+    rng = np.random.default_rng(0)
+    ctxs = ctx - (rng.integers(0, jitter + 1, B) if jitter else np.zeros(B, np.int64))
+    seq = torch.tensor(ctxs, dtype=torch.int32, device=dev)
+    qsl = torch.tensor(np.concatenate([[0], np.cumsum(ql)]).astype(np.int32), device=dev)
+    out = torch.empty_like(q)
+    rs = ops.split_requests(ql, Hq // Hkv, dev)
+    i = [0]
+
+    def f():
+        kv = kvs[i[0] % layers]
+        i[0] += 1
+        ops.verify_attention(q, kv[0], kv[1], bt, seq, qsl, max(ql), ctx, D ** -0.5, out=out, req_split=rs)
+    us = timeit(f)
+    gb = float(ctxs.sum()) * 2 * Hkv * D * 2 / 1e9
+    hist = {k: ql.count(k) for k in sorted(set(ql))}
+    print(f"attn-ql {hist} ctx<={ctx} jitter={jitter} short/long={rs[1]}/{rs[3]}: {us:8.1f} us  {gb / us * 1e6 / 1e3:6.2f} TB/s (incl. combine)")
 
 
 def attn_trace(n_short=59, n_long=5, q_short=1, q_long=33, ctx=4224, Hq=32, Hkv=8, D=128, bs=16):
@@ -214,9 +240,33 @@ if __name__ == "__main__":
         attn(B=16, qlen=33, split=True, kv8=True)      # verify_attn_long4_kernel<true, 128>
         attn(B=64, Hq=64, Hkv=8, D=64)                 # verify_attn_long4_kernel<false, 64>: head size 64
         timeit = _t
+    if "mid" in what:      # suffix drafts of 4-7 tokens (17-32 query rows): two row tiles of the short body since r02
+        attn_mix(64, 0)
+        attn_mix(59, 5, q_long=8)
+        attn_mix(59, 5, q_long=5)
+        attn_mix(59, 5, q_long=9)
+        attn_mix(59, 5, q_long=33)
+        attn_mix(57, 7, q_long=8)
+        attn_mix(30, 2, q_long=8)
+        attn_mix(30, 2, q_long=33)
+        attn_mix(59, 5, q_long=8, Hq=4, Hkv=1)
+        attn_mix(59, 5, q_long=33, Hq=4, Hkv=1)
+        attn_mix(64, 0, q_short=8)         # every request at two row tiles
+        attn_mix(64, 0, q_short=4)
+    if "ql" in what:
+        for jit in (0, 256):
+            attn_ql([1] * 64, jitter=jit)
+            attn_ql([1] * 59 + [6] * 3 + [20] * 2, jitter=jit)
+            attn_ql([1] * 59 + [8] * 3 + [33] * 2, jitter=jit)
+            attn_ql([1] * 61 + [6] * 3, jitter=jit)
+            attn_ql([1] * 62 + [20] * 2, jitter=jit)
+            attn_ql([1] * 63 + [33], jitter=jit)
+            attn_ql([1] * 58 + [5, 7, 8, 10, 20, 33], jitter=jit)
     if "trace" in what:
         attn_trace(59, 5)
         attn_trace(56, 8)
+        attn_trace(62, 2)
+        attn_trace(63, 1)
     if "mix" in what:
         attn_mix(64, 0)
         attn_mix(59, 5)
