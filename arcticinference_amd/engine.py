@@ -16,8 +16,8 @@ host touches the step's results and runs while the host updates the suffix trees
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-import itertools
-from typing import Dict, List, Optional, Sequence
+from collections.abc import Sequence
+from typing import Dict, List, Optional
 
 import numpy as np
 import torch
@@ -75,8 +75,9 @@ class _PendingDrafts:
     their VALUES on the host (it fills them into its input ids on the device), so nobody waits for this copy on the
     critical path; whoever reads `RequestState.drafts` first resolves it."""
 
-    def __init__(self, pinned: torch.Tensor, event, rows):
-        self.pinned, self.event, self.rows = pinned, event, rows     # rows: [(request, row in the LSTM output, k)]
+    def __init__(self, eng, pinned: torch.Tensor, event, slots: np.ndarray, rows: np.ndarray, ks: np.ndarray):
+        self.eng, self.pinned, self.event = eng, pinned, event
+        self.slots, self.rows, self.ks = slots, rows, ks     # slot, row in the LSTM output, number of tokens
         self.done = False
 
     def resolve(self) -> None:
@@ -85,43 +86,77 @@ class _PendingDrafts:
         self.done = True
         self.event.synchronize()
         host = self.pinned.numpy()
-        for r, row, k in self.rows:
-            if r._pending is self:
-                r._drafts = host[row, :k].tolist()
-                r._pending = None
+        e = self.eng
+        for slot, row, k in zip(self.slots.tolist(), self.rows.tolist(), self.ks.tolist()):
+            if e._pending[slot] is self:
+                e.draft_ids[slot, :k] = host[row, :k]
+                e._pending[slot] = None
+                e.draft_row[slot] = -1
 
 
 class RequestState:
-    __slots__ = ("req_id", "tokens", "num_prompt", "_drafts", "_pending", "draft_row", "blocks")
+    """One live request.  Its state lives in the engine's per-slot arrays (vLLM's InputBatch layout: token_ids_cpu,
+    num_tokens, the scheduled spec token ids), which is what lets a step's host work run on whole-batch array
+    operations; this object is the per-request view of them."""
+    __slots__ = ("req_id", "slot", "num_prompt", "_eng")
 
-    def __init__(self, req_id, prompt: Sequence[int], blocks: np.ndarray):
-        self.req_id = req_id
-        # prompt + every sampled token (token_ids_cpu row), as Python ints (a numpy prompt converts in one C pass:
-        # list(ndarray) makes 4096 numpy scalars, ~0.2 ms of a replacement's admission)
-        self.tokens: List[int] = prompt.tolist() if isinstance(prompt, np.ndarray) else [int(t) for t in prompt]
-        self.num_prompt = len(prompt)
-        self._drafts: List[int] = []
-        self._pending: Optional[_PendingDrafts] = None
-        self.draft_row = -1                      # row of this request in the LSTM output its drafts come from
-        self.blocks = blocks
+    def __init__(self, eng, slot: int, req_id, num_prompt: int):
+        self._eng, self.slot, self.req_id, self.num_prompt = eng, slot, req_id, num_prompt
+
+    @property
+    def num_tokens(self) -> int:
+        return int(self._eng.num_tokens[self.slot])
+
+    @property
+    def tokens(self) -> np.ndarray:
+        """prompt + every sampled token (a view of the token_ids_cpu row)"""
+        return self._eng.token_ids_cpu[self.slot, :self._eng.num_tokens[self.slot]]
+
+    @property
+    def blocks(self) -> np.ndarray:
+        return self._eng._free_blocks[self.slot]
 
     @property
     def drafts(self) -> List[int]:
         """Draft token ids scheduled for the next step (spec_token_ids).  LSTM drafts may still be in flight from the
         device; reading them here waits for that copy."""
-        if self._pending is not None:
-            self._pending.resolve()
-        return self._drafts
+        e = self._eng
+        if e._pending[self.slot] is not None:
+            e._pending[self.slot].resolve()
+        return e.draft_ids[self.slot, :e.n_draft[self.slot]].tolist()
 
     @drafts.setter
-    def drafts(self, value: List[int]) -> None:
-        self._drafts = value
-        self._pending = None
-        self.draft_row = -1
+    def drafts(self, value: Sequence[int]) -> None:
+        e = self._eng
+        e.n_draft[self.slot] = len(value)
+        e.draft_ids[self.slot, :len(value)] = value
+        e._pending[self.slot] = None
+        e.draft_row[self.slot] = -1
 
     @property
     def num_drafts(self) -> int:
-        return len(self._drafts)
+        return int(self._eng.n_draft[self.slot])
+
+
+class Emitted(Sequence):
+    """Tokens emitted per request of a step: behaves like a list of lists; `flat` / `counts` are the arrays behind it."""
+
+    def __init__(self, flat: np.ndarray, counts: np.ndarray):
+        self.flat, self.counts = flat, counts
+        self._cu = np.concatenate([[0], np.cumsum(counts)])
+
+    def __len__(self) -> int:
+        return len(self.counts)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        return self.flat[self._cu[i]:self._cu[i + 1]].tolist()
+
+    def __eq__(self, other):
+        return list(self) == list(other)
 
 
 class HotPathEngine:
@@ -173,8 +208,16 @@ class HotPathEngine:
         self._free_blocks = [perm[i * self.blocks_per_seq:(i + 1) * self.blocks_per_seq] for i in range(max_num_seqs)]
         self._bt_host = np.stack(self._free_blocks)       # [max_num_seqs, blocks_per_seq]: a slot's pages never change
         self.requests: List[Optional[RequestState]] = [None] * max_num_seqs
-        # vLLM's input_batch.token_ids_cpu: prompt + sampled tokens per slot (the suffix patterns are slices of it)
+        # vLLM's input_batch.token_ids_cpu / num_tokens: prompt + sampled tokens per slot (the suffix patterns are slices
+        # of it), and the spec token ids scheduled for the next step
         self.token_ids_cpu = np.zeros((max_num_seqs, max_model_len + MAX_SPEC_LEN + 2), dtype=np.int32)
+        self.num_tokens = np.zeros(max_num_seqs, dtype=np.int32)
+        self.num_prompt = np.zeros(max_num_seqs, dtype=np.int32)
+        self.n_draft = np.zeros(max_num_seqs, dtype=np.int32)
+        self.draft_ids = np.zeros((max_num_seqs, MAX_SPEC_LEN), dtype=np.int32)
+        self.draft_row = np.full(max_num_seqs, -1, dtype=np.int64)    # row of the in-flight LSTM output, -1: ids are on the host
+        self._pending: List[Optional[_PendingDrafts]] = [None] * max_num_seqs
+        self._req_ids: List = [None] * max_num_seqs
         self.block_table = torch.from_numpy(self._bt_host).to(self.device)   # int32 [max_num_seqs, blocks_per_seq]
         self.sm_scale = s.head_size ** -0.5
         self._plant_col = torch.full((self.max_tokens, 1), 30.0, dtype=torch.bfloat16, device=self.device)
@@ -183,25 +226,33 @@ class HotPathEngine:
         self.timeline: Dict[str, float] = {}   # seconds accumulated per phase (host clock)
 
     # -- request management ---------------------------------------------------------------------------
+    def _admit(self, slot: int, req_id, prompt_arr: np.ndarray, gen: np.ndarray) -> RequestState:
+        r = RequestState(self, slot, req_id, len(prompt_arr))
+        self.requests[slot] = r
+        self._req_ids[slot] = req_id
+        n = len(prompt_arr)
+        self.token_ids_cpu[slot, :n] = prompt_arr
+        self.token_ids_cpu[slot, n:n + len(gen)] = gen
+        self.num_tokens[slot] = n + len(gen)
+        self.num_prompt[slot] = n
+        self.n_draft[slot] = 0
+        self.draft_row[slot] = -1
+        self._pending[slot] = None
+        return r
+
     def add_request(self, slot: int, req_id, prompt: Sequence[int], first_token) -> None:
         """Admit a request whose prompt has been prefilled (its KV is taken as resident) and whose first
         token has been sampled (`first_token`: that token, or the list of tokens generated so far for a request
         that joins mid-generation).  Mirrors the first pass through _update_suffix_cache (:657-673); the prompt tree
         is built on a host thread while the next step's attention runs (SuffixCache.cache_prompt_async)."""
         old = self.requests[slot]
-        blocks = self._free_blocks[slot]
-        r = RequestState(req_id, prompt, blocks)
-        self.requests[slot] = r
         gen = np.asarray([first_token] if np.isscalar(first_token) else first_token, dtype=np.int32).reshape(-1)
         prompt_arr = np.asarray(prompt, dtype=np.int32)
         if self.suffix_cache is not None:
             if old is not None and self.suffix_cache.has_cached_prompt(old.req_id):
                 self.suffix_cache.evict_prompt(old.req_id)   # model_runner.py:675-678
             self.suffix_cache.cache_prompt_async(req_id, prompt_arr, gen)
-        r.tokens.extend(gen.tolist())
-        n = r.num_prompt
-        self.token_ids_cpu[slot, :n] = prompt_arr
-        self.token_ids_cpu[slot, n:n + len(gen)] = gen
+        self._admit(slot, req_id, prompt_arr, gen)
 
     def add_requests(self, slots, req_ids, prompts, first_tokens, n_threads: int = 8) -> None:
         if self.suffix_cache is not None:
@@ -211,13 +262,10 @@ class HotPathEngine:
                     self.suffix_cache.evict_prompt(old.req_id)
             self.suffix_cache.cache_prompts(list(req_ids), [list(p) for p in prompts], n_threads=n_threads)
         for s, rid, p, ft in zip(slots, req_ids, prompts, first_tokens):
-            r = RequestState(rid, p, self._free_blocks[s])
-            self.requests[s] = r
-            gen = [int(ft)] if np.isscalar(ft) else [int(t) for t in ft]
+            gen = np.asarray([ft] if np.isscalar(ft) else ft, dtype=np.int32).reshape(-1)
             if self.suffix_cache is not None:
-                self.suffix_cache.update_response(rid, gen)
-            r.tokens.extend(gen)
-            self.token_ids_cpu[s, :len(r.tokens)] = r.tokens
+                self.suffix_cache.update_response(rid, gen.tolist())
+            self._admit(s, rid, np.asarray(p, dtype=np.int32), gen)
 
     # -- one engine step --------------------------------------------------------------------------------
     def step(self, next_truth) -> List[List[int]]:
@@ -271,19 +319,21 @@ class HotPathEngine:
             _state[0] = now
         L = self._lane(lane)
         s, spec, dev = self.shape, self.spec, self.device
-        cand = range(len(self.requests)) if only_slots is None else only_slots
-        live = [i for i in cand if self.requests[i] is not None]
+        rq = self.requests            # the list is the scheduler's: a slot set to None has left the batch
+        cand = range(len(rq)) if only_slots is None else only_slots
+        live = np.fromiter((i for i in cand if rq[i] is not None), dtype=np.int64)
         B = len(live)
         if B == 0:
             return None
-        reqs = [self.requests[i] for i in live]
-        n_draft = np.fromiter((len(r._drafts) for r in reqs), dtype=np.int32, count=B)
+        reqs = [rq[i] for i in live]
+        n_draft = self.n_draft[live]
         q_len = n_draft + 1
         T = int(q_len.sum())
         qsl = np.zeros(B + 1, dtype=np.int32)
         np.cumsum(q_len, out=qsl[1:])
         # context after this step's tokens are written: everything sampled so far + the drafts
-        ctx = np.fromiter((len(r.tokens) for r in reqs), dtype=np.int32, count=B) + n_draft
+        ntok = self.num_tokens[live]
+        ctx = ntok + n_draft
         max_q, max_ctx = int(q_len.max()), int(ctx.max())
         if getattr(self, "qlen_hist", None) is not None:      # diagnostic (bench.py --qlen-hist): query lengths seen
             self.qlen_hist += np.bincount(q_len, minlength=len(self.qlen_hist))[:len(self.qlen_hist)]
@@ -293,11 +343,10 @@ class HotPathEngine:
         # only the acceptance needs — draft ids, the synthetic target's tokens, target / bonus row indices — is built
         # while the GPU is already attending (rocprofv3 timeline of the r02 bench: 0.58 ms of GPU idle sat between the
         # suffix kernels of one step and the staging copy of the next; building B first was a third of it).
-        slot_map = self._slot_mapping(live, reqs, q_len, qsl, T)
+        slot_map = self._slot_mapping(live, ntok, q_len, qsl, T)
         G = self.hq_local // self.hkv_local
         order, n_short_reqs = ops.split_order(q_len, G)            # short / long request lists of the attention call
-        stA = self._stage(L, "A", [(ctx, np.int32), (qsl, np.int32), (np.asarray(live), np.int64), (slot_map, np.int64),
-                                (order, np.int32)])
+        stA = self._stage(L, "A", [(ctx, np.int32), (qsl, np.int32), (live, np.int64), (slot_map, np.int64), (order, np.int32)])
         d_seq, d_qsl, slots, d_slots, order_dev = stA
         bt = self.block_table.index_select(0, slots) if B != self.max_num_seqs else self.block_table
 
@@ -314,16 +363,14 @@ class HotPathEngine:
         # planted verify logits: row (request i, position p) gets the target's token for that position
         ql = q_len.tolist()
         plant_tok = np.concatenate([next_truth(r, ql[i]) for i, r in enumerate(reqs)]).astype(np.int64, copy=False)
-        # draft ids: suffix drafts are host lists; LSTM drafts of the previous step are still on the device (their
+        # draft ids: suffix drafts are on the host; LSTM drafts of the previous step are still on the device (their
         # host copy is in flight and nobody waits for it here): placeholders now, filled on the device below
-        n_draft_total = int(n_draft.sum())
-        draft_flat = np.fromiter(itertools.chain.from_iterable(r._drafts for r in reqs), dtype=np.int32, count=n_draft_total)
+        draft_flat = self.draft_ids[live][np.arange(MAX_SPEC_LEN)[None, :] < n_draft[:, None]]
         cu_draft = np.cumsum(n_draft)
         fill_pos = fill_src = np.zeros(0, np.int64)
         prev_lstm = L.lstm_prev
         if prev_lstm is not None:
-            pend_rows = np.fromiter((r.draft_row if (r._pending is not None and not r._pending.done) else -1 for r in reqs),
-                                    dtype=np.int64, count=B)
+            pend_rows = self.draft_row[live]
             sel = np.nonzero(pend_rows >= 0)[0]
             if len(sel):
                 k_sel = n_draft[sel].astype(np.int64)
@@ -373,7 +420,7 @@ class HotPathEngine:
                                                        hidden_index=rej.hidden_index)
         _mark('enqueue_accept_and_draft')
         return SimpleNamespace(lane=L, live=live, reqs=reqs, B=B, n_draft=n_draft, out_pin=out_pin, rej=rej, lstm_out=lstm_out,
-                               use_lstm=use_lstm)
+                               use_lstm=use_lstm, ntok=ntok)
 
     def finish(self, c) -> List[List[int]]:
         """Host half of the step begun as `c`: returns the tokens emitted per request of that step."""
@@ -386,30 +433,30 @@ class HotPathEngine:
         s, spec, dev = self.shape, self.spec, self.device
         L, live, reqs, B, n_draft, out_pin, rej, lstm_out, use_lstm = (c.lane, c.live, c.reqs, c.B, c.n_draft, c.out_pin, c.rej,
                                                                       c.lstm_out, c.use_lstm)
+        req_ids = [self._req_ids[i] for i in live.tolist()]
         if self.suffix_cache is not None and B <= spec.disable_by_batch_size:
             # the trees went cold during the step: read what the update will touch while the GPU still works
             # (after the wait instead, the same reads cost 0.055 ms and buy back no more than that)
-            self.suffix_cache.warm([r.req_id for r in reqs])
+            self.suffix_cache.warm(req_ids)
         L.out_ev.synchronize()                           # the step's only blocking wait before the proposals
         out_host = out_pin.numpy()
         _mark('wait_gpu_accept')
 
-        # (e) host: parse, commit, update the suffix trees while the LSTM kernels run
+        # (e) host: parse, commit, update the suffix trees while the LSTM kernels run — whole-batch array operations
         valid = (out_host != -1) & (out_host < s.vocab_size)                  # parse_output (:456-459)
         n_emit = valid.sum(axis=1).astype(np.int32)
         flat_emit = out_host[valid]                                            # row-major: request by request
-        emitted: List[List[int]] = []
-        at = 0
-        live_arr = np.asarray(live)
-        for i, r in enumerate(reqs):
-            k = int(n_emit[i])
-            toks = flat_emit[at:at + k].tolist()
-            at += k
-            emitted.append(toks)
-            self.token_ids_cpu[live[i], len(r.tokens):len(r.tokens) + k] = toks
-            r.tokens.extend(toks)
-            r.drafts = []
-        self.stats.emitted += int(n_emit.sum())
+        n_total = len(flat_emit)
+        ntok = c.ntok
+        first = np.cumsum(n_emit) - n_emit
+        within = np.arange(n_total) - np.repeat(first, n_emit)
+        self.token_ids_cpu[np.repeat(live, n_emit), np.repeat(ntok, n_emit) + within] = flat_emit
+        ntok = ntok + n_emit
+        self.num_tokens[live] = ntok
+        self.n_draft[live] = 0
+        self.draft_row[live] = -1
+        emitted = Emitted(flat_emit, n_emit)
+        self.stats.emitted += n_total
         had = n_draft > 0
         self.stats.num_drafts += int(had.sum())
         self.stats.drafted += int(n_draft.sum())
@@ -419,14 +466,14 @@ class HotPathEngine:
         _mark('host_parse')
         suffix = None
         if self.suffix_cache is not None:
-            self.suffix_cache.update_responses([r.req_id for r in reqs], flat_emit, n_emit)   # _update_suffix_cache (:657-678)
+            self.suffix_cache.update_responses(req_ids, flat_emit, n_emit)   # _update_suffix_cache (:657-678)
             _mark('host_suffix_update')
             # the tree mirror update + match kernels need nothing from the main stream (their input is the host
             # tree): on a side stream they run beside the LSTM draft instead of queueing behind it
             if not hasattr(self, "_suffix_stream"):
                 self._suffix_stream = torch.cuda.Stream(device=dev)
             with torch.cuda.stream(self._suffix_stream):
-                suffix = self._propose_suffix(live_arr, reqs, n_emit)
+                suffix = self._propose_suffix(live, req_ids, ntok, n_emit)
             _mark('suffix_speculate_roundtrip')
         # (f) merge (:555-566, :595-601).  The LSTM tokens start their copy to the host (the reference's `.cpu()`,
         # arctic_proposer.py:166) but nothing here waits for it: which requests take the LSTM draft, and how many
@@ -444,9 +491,9 @@ class HotPathEngine:
             elif lstm_out is None:
                 lstm_out = self.drafter.generate_proposals(rej.last_token, self.hidden, spec.num_speculative_tokens,
                                                            hidden_index=rej.hidden_index)
-        pend = None
         self.stats.steps += 1
         self.stats.draft_model_steps += lstm_out is not None
+        pin = ev = None
         if lstm_out is not None:
             if L.lstm_pin is None or L.lstm_pin[0].shape[1] != lstm_out.shape[1]:
                 L.lstm_pin = [torch.empty(self.max_num_seqs, lstm_out.shape[1], dtype=lstm_out.dtype).pin_memory()
@@ -456,27 +503,35 @@ class HotPathEngine:
             pin.copy_(lstm_out, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            pend = _PendingDrafts(pin, ev, [])
         L.lstm_prev = lstm_out
         _mark('host_draft_copy')
-        # the draft model's length clamp is ONE value for the batch in the reference (the running minimum of
-        # propose_arctic_draft_token_ids, model_runner.py:629-641); the per-request extension clamps per request
-        k_batch = spec.num_speculative_tokens
-        if pend is not None and not spec.draft_model_per_request:
-            k_batch = max(min(k_batch, self.max_model_len - max(len(r.tokens) for r in reqs) - 1), 0)
-        for i, r in enumerate(reqs):
-            room = self.max_model_len - len(r.tokens) - 1
-            if took is not None and took[i]:
-                r.drafts = suffix[0][i, :suffix[1][i]].tolist()[:max(room, 0)]
-                self.stats.suffix_used += 1
-            elif pend is not None and n_emit[i]:
-                k = max(min(k_batch, room), 0)
-                r.drafts = [0] * k                          # placeholders until the copy lands
-                if k:
-                    r._pending, r.draft_row = pend, i
-                    pend.rows.append((r, i, k))
-            else:
-                r.drafts = []
+        room = np.maximum(self.max_model_len - ntok - 1, 0)
+        if suffix_won:
+            idx = np.flatnonzero(took)
+            rows = live[idx]
+            w = min(suffix[0].shape[1], MAX_SPEC_LEN)
+            self.draft_ids[rows, :w] = suffix[0][idx, :w]
+            self.n_draft[rows] = np.minimum(suffix[1][idx], room[idx])
+            self.stats.suffix_used += len(idx)
+        if pin is not None:
+            # the draft model's length clamp is ONE value for the batch in the reference (the running minimum of
+            # propose_arctic_draft_token_ids, model_runner.py:629-641); the per-request extension clamps per request
+            k_batch = spec.num_speculative_tokens
+            if not spec.draft_model_per_request:
+                k_batch = max(min(k_batch, self.max_model_len - int(ntok.max()) - 1), 0)
+            gets = n_emit > 0
+            if took is not None:
+                gets &= ~took
+            idx = np.flatnonzero(gets)
+            ks = np.minimum(k_batch, room[idx]).astype(np.int32)
+            idx, ks = idx[ks > 0], ks[ks > 0]
+            rows = live[idx]
+            self.n_draft[rows] = ks
+            self.draft_ids[rows, :spec.num_speculative_tokens] = 0      # placeholders until the copy lands
+            self.draft_row[rows] = idx
+            pend = _PendingDrafts(self, pin, ev, rows, idx, ks)
+            for slot in rows.tolist():
+                self._pending[slot] = pend
         _mark('host_merge')
         return emitted
 
@@ -503,23 +558,25 @@ class HotPathEngine:
         dev[:nbytes].copy_(pin[:nbytes], non_blocking=True)
         return [dev[o:o + len(a) * np.dtype(k).itemsize].view(self._TORCH_OF[np.dtype(k)]) for (a, k), o in zip(arrays, offs)]
 
-    def _propose_suffix(self, live_arr, reqs, n_emit):
+    def _propose_suffix(self, live, req_ids, end, n_emit):
         """propose_suffix_draft_token_ids (model_runner.py:680-744) for the whole batch at once, on arrays.
-        Returns (tokens [B, cap], n_tokens [B], score [B]); requests that are skipped keep n_tokens = 0."""
+        `end` = tokens per request after this step's.  Returns (tokens [B, cap], n_tokens [B], score [B]); requests that
+        are skipped keep n_tokens = 0."""
         cfg = self.spec
-        B = len(reqs)
-        end = np.fromiter((len(r.tokens) for r in reqs), dtype=np.int64, count=B)
+        B = len(live)
+        end = end.astype(np.int64)
         depth = cfg.suffix_cache_max_depth
         ask = (n_emit > 0) & (end < self.max_model_len)
-        where = np.nonzero(ask)[0]
         n_tok = np.zeros(B, np.int32)
         score = np.zeros(B, np.float32)
         toks = np.zeros((B, 1), np.int32)
+        everyone = bool(ask.all())
+        where = np.arange(B) if everyone else np.nonzero(ask)[0]
         if len(where) == 0:
             return toks, n_tok, score
-        e = end[where]
+        e = end if everyone else end[where]
         size = np.minimum(e, depth)
-        rows = live_arr[where]
+        rows = live if everyone else live[where]
         if int(size.min()) == depth:      # the usual case: every pattern is the full last `depth` tokens
             idx = (e - depth)[:, None] + np.arange(depth)[None, :]
             flat = self.token_ids_cpu[rows[:, None], idx].reshape(-1)
@@ -527,25 +584,29 @@ class HotPathEngine:
             flat = np.concatenate([self.token_ids_cpu[rw, x - z:x] for rw, x, z in zip(rows, e, size)])
         mst = np.minimum(min(MAX_SPEC_LEN, depth), self.max_model_len - e - 1).astype(np.int32)
         nq = len(where)
+        consts = self.__dict__.setdefault("_suffix_consts", {})
+        if nq not in consts:
+            consts[nq] = (np.full(nq, cfg.suffix_max_spec_factor, np.float32), np.full(nq, cfg.suffix_max_spec_offset, np.float32),
+                          np.full(nq, cfg.suffix_min_token_prob, np.float32), np.ones(nq, np.int32))
         o_tok, _, o_n, o_sc, _ = self.suffix_cache.speculate_batch_arrays(
-            [reqs[i].req_id for i in where], flat, size.astype(np.int32), mst,
-            np.full(nq, cfg.suffix_max_spec_factor, np.float32), np.full(nq, cfg.suffix_max_spec_offset, np.float32),
-            np.full(nq, cfg.suffix_min_token_prob, np.float32), np.ones(nq, np.int32))
-        toks = np.zeros((B, o_tok.shape[1]), np.int32)
-        toks[where] = o_tok
-        n_tok[where] = o_n
-        score[where] = o_sc
+            req_ids if everyone else [req_ids[i] for i in where], flat, size.astype(np.int32), mst, *consts[nq])
+        if everyone:
+            toks, n_tok, score = o_tok, o_n.astype(np.int32, copy=False), o_sc.astype(np.float32, copy=False)
+        else:
+            toks = np.zeros((B, o_tok.shape[1]), np.int32)
+            toks[where] = o_tok
+            n_tok[where] = o_n
+            score[where] = o_sc
         self.last_suffix_stats = self.suffix_cache.last_stats()
         return toks, n_tok, score
 
-    def _slot_mapping(self, live, reqs, q_len, qsl, T) -> np.ndarray:
+    def _slot_mapping(self, live, ntok, q_len, qsl, T) -> np.ndarray:
         """KV slot of every token of the step (one vectorised pass: row i covers positions first_i .. first_i + q_len_i - 1,
         first_i = position of the last sampled token, which is not in the cache yet)."""
         bs = self.shape.block_size
-        first = np.fromiter((len(r.tokens) - 1 for r in reqs), dtype=np.int64, count=len(reqs))
-        rep = np.repeat(np.arange(len(reqs)), q_len)
-        pos = first[rep] + (np.arange(T) - qsl[:-1][rep])
-        return self._bt_host[np.asarray(live)[rep], pos // bs].astype(np.int64) * bs + pos % bs
+        rep = np.repeat(np.arange(len(live)), q_len)
+        pos = (ntok.astype(np.int64) - 1)[rep] + (np.arange(T) - qsl[:-1][rep])
+        return self._bt_host[live[rep], pos // bs].astype(np.int64) * bs + pos % bs
 
     def _write_kv(self, d_slots, T) -> None:
         s = self.shape

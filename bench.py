@@ -278,7 +278,7 @@ def main():
 
     def truth(r, n):
         s = streams[r.req_id]
-        p = len(r.tokens)
+        p = r.num_tokens
         return s[p:p + n]
 
     gen_tokens = [0]
@@ -288,16 +288,16 @@ def main():
     kvb = 2 if args.kv_dtype == "auto" else 1
 
     def account(slots_live, emitted):
-        for slot, toks in zip(slots_live, emitted):
-            r = eng.requests[slot]
-            done = len(r.tokens) - r.num_prompt
-            over = max(0, done - GL)
-            gen_tokens[0] += len(toks) - min(over, len(toks))
-            if done >= GL:
-                streams.pop(r.req_id, None)
-                rid, prompt, ft = new_request()
-                eng.add_request(slot, rid, prompt, ft)   # prompt tree of the new request (model_runner.py:664-671)
-                replaced[0] += 1
+        """Count the step's tokens (those past a request's gen_len are not generated tokens) and replace the requests
+        that finished."""
+        done = eng.num_tokens[slots_live] - eng.num_prompt[slots_live]
+        counts = emitted.counts
+        gen_tokens[0] += int((counts - np.minimum(np.maximum(done - GL, 0), counts)).sum())
+        for slot in slots_live[done >= GL].tolist():
+            streams.pop(eng.requests[slot].req_id, None)
+            rid, prompt, ft = new_request()
+            eng.add_request(slot, rid, prompt, ft)   # prompt tree of the new request (model_runner.py:664-671)
+            replaced[0] += 1
 
     n_lanes = max(1, min(args.lanes, B))
     lane_slots = [list(range(l, B, n_lanes)) for l in range(n_lanes)]

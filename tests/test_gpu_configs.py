@@ -229,7 +229,7 @@ def test_opt125m_suffix_only_engine_loop():
             assert emitted[i] == [int(x) for x in streams[r.req_id][before[i]:before[i] + len(emitted[i])]]
             orc.update_response(r.req_id, emitted[i])
         for r in eng.requests:
-            want = orc.speculate(r.req_id, r.tokens[-64:], max_spec_tokens=min(MAX_SPEC_LEN, 64, limit - len(r.tokens) - 1))
+            want = orc.speculate(r.req_id, r.tokens[-64:].tolist(), max_spec_tokens=min(MAX_SPEC_LEN, 64, limit - len(r.tokens) - 1))
             assert r.drafts == want.token_ids
             long_drafts += len(want.token_ids) > 3
     assert long_drafts > 0 and eng.stats.accepted > 0

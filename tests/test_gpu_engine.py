@@ -68,7 +68,7 @@ def test_engine_steps_match_oracle_policy(method, with_lstm, head_size, per_requ
             assert len(toks) == want_acc + 1
             orc.update_response(r.req_id, toks)
         # the reference updates the cache for the whole batch first (_update_suffix_cache), then proposes
-        wants = [orc.speculate(r.req_id, r.tokens[-64:], max_spec_tokens=min(MAX_SPEC_LEN, 64, 400 - len(r.tokens) - 1))
+        wants = [orc.speculate(r.req_id, r.tokens[-64:].tolist(), max_spec_tokens=min(MAX_SPEC_LEN, 64, 400 - len(r.tokens) - 1))
                  for r in eng.requests]
         takes = [bool(w.score >= min_score and w.token_ids) for w in wants]
         for i, r in enumerate(eng.requests):
@@ -157,7 +157,7 @@ def test_two_interleaved_lanes_follow_the_reference_policy_per_lane_step(method,
                 for r, toks, b0 in zip(c.reqs, emitted, before):
                     assert toks == [int(x) for x in streams[r.req_id][b0:b0 + len(toks)]]
                     orc.update_response(r.req_id, toks)
-                wants = [orc.speculate(r.req_id, r.tokens[-64:], max_spec_tokens=min(MAX_SPEC_LEN, 64, 400 - len(r.tokens) - 1))
+                wants = [orc.speculate(r.req_id, r.tokens[-64:].tolist(), max_spec_tokens=min(MAX_SPEC_LEN, 64, 400 - len(r.tokens) - 1))
                          for r in c.reqs]
                 takes = [bool(w.score >= min_score and w.token_ids) for w in wants]
                 for r, w, t in zip(c.reqs, wants, takes):
