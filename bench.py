@@ -56,13 +56,13 @@ def parse_args():
     ap.add_argument("--kv-dtype", default="auto", choices=["auto", "fp8"], help="KV cache dtype (auto = bf16, the headline config)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--qlen-hist", action="store_true", help="diagnostic: histogram of per-request query lengths in the timed steps")
-    ap.add_argument("--lanes", type=int, default=1,
-                    help="1 (default): every request in one engine step per round (host chain and GPU alternate).  2: the "
-                         "live requests form two lanes of B/2 whose steps are interleaved — one lane's host chain (tree "
-                         "update, suffix proposal, index build) runs while the GPU attends for the other; a round still "
-                         "advances every request by one step (measured r02: 6.97 against 7.22 ms per round over 60 rounds; "
-                         "a 32-request attention launch is 8 % less efficient per byte than a 64-request one, and lane "
-                         "steps without a suffix winner run the draft model, so the gain is 3-4 %)")
+    ap.add_argument("--lanes", type=int, default=0,
+                    help="2: the live requests form two lanes of B/2 whose engine steps are interleaved — one lane's host "
+                         "chain (tree update, suffix proposal, index build) runs while the GPU attends for the other; a "
+                         "round still advances every request by one step.  1: every request in one engine step per round "
+                         "(host chain and GPU alternate).  0 (default): 2 on one GPU, 1 under SP, where the step is "
+                         "bound by the replicated host work and a second lane adds to it (measured r02, ms per round, 1 / 2 "
+                         "lanes: one GPU 7.00 / 6.68; rehearsed SP 2: 4.22 / 4.13, SP 4: 2.81 / 2.74, SP 8: 2.30 / 2.48)")
     ap.add_argument("--draft-model-per-request", action="store_true",
                     help="extension: requests that suffix decoding did not take still get the draft model's proposal in "
                          "steps where it took others (the reference gives the whole batch none, model_runner.py:616-618)")
@@ -299,7 +299,9 @@ def main():
             eng.add_request(slot, rid, prompt, ft)   # prompt tree of the new request (model_runner.py:664-671)
             replaced[0] += 1
 
-    n_lanes = max(1, min(args.lanes, B))
+    sp_ways = world if world > 1 else max(args.rehearse_sp, 1)
+    n_lanes = args.lanes if args.lanes > 0 else (2 if sp_ways == 1 else 1)
+    n_lanes = max(1, min(n_lanes, B))
     lane_slots = [list(range(l, B, n_lanes)) for l in range(n_lanes)]
     pending = [None] * n_lanes
 
@@ -404,7 +406,10 @@ def main():
             if default_shape and os.path.exists(pmc):
                 try:
                     with open(pmc) as f:
-                        traffic = json.load(f).get("hbm_bytes_per_launch")
+                        summary = json.load(f)
+                    if summary.get("lanes", 1) != n_lanes:      # collected under another schedule: other launches
+                        continue
+                    traffic = summary.get("hbm_bytes_per_launch")
                     traffic_source = "profiles/" + name + " (separate rocprofv3 --pmc passes, tools/pmc_summary.py; not this run)"
                     break
                 except Exception:
@@ -438,6 +443,7 @@ def main():
                              "attention, acceptance, suffix + LSTM proposal, KV write); target dense layers synthetic"
                              % (shape.num_layers, B, PL, GL, "bf16" if args.kv_dtype == "auto" else "fp8 e4m3")),
                 "global_batch": B, "prompt_len": PL, "gen_len": GL,
+                "lanes": n_lanes,
                 "schedule": ("one engine step over all %d requests per round" % B if n_lanes == 1 else
                              "%d lanes of %d requests, steps interleaved (one lane's host chain under the other's attention); "
                              "a round = every request advances one step" % (n_lanes, B // n_lanes)),

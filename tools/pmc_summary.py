@@ -48,10 +48,16 @@ def main():
         wr = 1024.0 * sum(w) / max(len(w), 1)
         res[name] = {"launches": len(f), "fetch_size_raw_kb_avg": sum(f) / len(f), "write_size_kb_avg": sum(w) / max(len(w), 1),
                      "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr}
-    dom = res.get("pair") or res.get("short")
+    # the bench's roofline figure averages over EVERY per-layer attention launch of the timed steps (pair kernel in steps
+    # with a long draft, short kernel otherwise): the traffic figure is the same average
+    kinds = [res[k] for k in ("pair", "short") if k in res]
+    n_all = sum(k["launches"] for k in kinds)
     res["kernel"] = "verify_attn_pair_kernel" if "pair" in res else "verify_attn_kernel"
-    res["hbm_bytes_per_launch"] = dom["hbm_read_bytes_per_launch"] + dom["hbm_write_bytes_per_launch"]
+    res["attention_launches"] = n_all
+    res["hbm_bytes_per_launch"] = sum((k["hbm_read_bytes_per_launch"] + k["hbm_write_bytes_per_launch"]) * k["launches"]
+                                      for k in kinds) / n_all
     res["algorithmic_bytes_per_launch"] = bench["roofline"]["algorithmic_bytes_per_launch"]
+    res["lanes"] = bench["config"].get("lanes", 1)
     json.dump(res, sys.stdout, indent=1)
     print()
 
