@@ -1232,7 +1232,7 @@ static int g_force_hpw = 0, g_force_splits = 0;   // aic_debug_attn_layout (tool
 // waves are HPW head groups of R = 4 / HPW token ranges each, merged through LDS) and cross-workgroup token splits.
 // One split means no partials at all: the workgroup that saw a row's whole context writes the finished row ("direct"),
 // and a call without long drafts needs no combine launch.
-// MEASURED (tools/microbench.py layout, profiles/r02_microbench.txt; 4224-token contexts, per call incl. combine):
+// MEASURED (tools/microbench.py layout, profiles/r02_microbench_earlier.txt; 4224-token contexts, per call incl. combine):
 //   64 requests: HPW 4 x 2 splits 172 us | HPW 2 x 1 split (direct, no combine) 179 us | HPW 1 x 1 split 202 us
 //   32 requests: HPW 4 x 4 splits  91 us | HPW 2 x 2 splits 96 us | HPW 1 x 1 split (direct) 104 us | HPW 2 x 1 143 us
 //   16 requests: HPW 4 x 8 splits  51 us | HPW 2 x 4 splits 53 us | HPW 1 x 2 splits 58 us
