@@ -18,7 +18,7 @@ import collections
 import ctypes
 import math
 from dataclasses import dataclass
-from typing import Dict, Iterable, Optional, Tuple
+from typing import Dict, Iterable, List, Optional, Tuple
 
 import torch
 
@@ -67,7 +67,8 @@ class ArcticLSTMSpeculator:
     def __init__(self, config: LSTMSpeculatorConfig, max_num_seqs: int = 64, tp_size: int = 1, tp_rank: int = 0,
                  tp_group=None, device: str = "cuda", quantize_lm_head: bool = True, use_graph: bool = False):
         if config.method != "sum_lstm":
-            raise NotImplementedError("only the sum_lstm speculator is on the MI355X path (SURVEY §8f-3)")
+            raise NotImplementedError(f"method '{config.method}': use lstm_family_speculator(), which builds the sum_rnn "
+                                      "form on the MLP-speculator kernels")
         assert config.tie_weights and config.tie_lstm_embs, "sum_lstm requires tied weights (arctic_speculator.py:545,663)"
         self.config = config
         self.n_predict = config.n_predict
@@ -446,3 +447,58 @@ def random_lstm_weights(cfg: LSTMSpeculatorConfig, seed: int = 0, std: float = 0
         w[f"{ln}.0.bias"] = (0.1 * torch.randn(Ds, generator=g)).to(torch.bfloat16).to(device)
     w["head.0.weight"] = r(V, Ds)
     return w
+
+
+def _dims(v) -> List[int]:
+    if isinstance(v, str):
+        return [int(x) for x in v.split(".")]
+    if isinstance(v, (list, tuple)):
+        return [int(x) for x in v]
+    return [int(v)]
+
+
+class ArcticSumRNNSpeculator(ArcticMLPSpeculator):
+    """ArcticLSTMSpeculator with method "sum_rnn" (the reference's default, arctic_speculator.py:441,476-543,691-703):
+    per head `states = proj(prev) + (emb_weight / state_weight) * emb(last_tokens); states = gelu(ln(states))` — the MLP
+    speculator's head with its own input width and Sequential-wrapped parameter names (`emb.{i}.0.weight`, `proj.{i}.0.weight`,
+    `ln.{i}.0.weight|bias`).  Same stage tying (emb / ln / head stage 0, proj stages 0 and 1, :653-654), same ln0 input
+    scaling, same vocab-parallel head and sharded embedding, so it runs on the MLP speculator's kernels unchanged.
+    The multi-entry dimension lists ("4096.4096": extra LayerNorm + GELU + Linear stacks inside emb / proj / ln, :478-542)
+    are not built: such a checkpoint is refused with a message."""
+
+    def __init__(self, config: LSTMSpeculatorConfig, **kw):
+        inner, emb, proj = _dims(config.inner_dim), _dims(config.emb_dim), _dims(config.proj_dim)
+        if len(inner) != 1 or len(emb) != 1 or len(proj) != 1:
+            raise NotImplementedError("sum_rnn speculators with stacked emb / proj / ln stages (dimension lists with more "
+                                      f"than one entry: emb {emb}, proj {proj}, inner {inner}) are not supported")
+        if not (inner[0] == emb[0] == proj[0]):
+            raise ValueError("sum_rnn adds proj(prev) and emb(tokens): proj_dim, emb_dim and inner_dim must be equal "
+                             "(arctic_speculator.py:693-699)")
+        self.lstm_config = config
+        super().__init__(MLPSpeculatorConfig(vocab_size=config.vocab_size, emb_dim=config.input_hidden_dim,
+                                             inner_dim=inner[0], n_predict=config.n_predict,
+                                             num_lookahead_tokens=config.num_lookahead_tokens,
+                                             tie_weights=config.tie_weights, scale_input=config.scale_input), **kw)
+
+    _SEQ = ("emb.", "proj.", "ln.")
+
+    def load_weights(self, weights: Iterable[Tuple[str, torch.Tensor]]):
+        def plain(name: str) -> str:
+            name = name.replace("speculator.", "")
+            for pre in self._SEQ:                      # emb.2.0.weight -> emb.2.weight (index 0 of the nn.Sequential)
+                if name.startswith(pre):
+                    parts = name.split(".")
+                    if len(parts) == 4 and parts[2] == "0":
+                        return ".".join(parts[:2] + parts[3:])
+            return name
+        return super().load_weights((plain(k), v) for k, v in weights)
+
+
+def lstm_family_speculator(config: LSTMSpeculatorConfig, **kw):
+    """The drafter for an ArcticLSTMSpeculator checkpoint by its `method` (arctic_speculator.py:441): "sum_lstm" or
+    "sum_rnn"."""
+    if config.method == "sum_lstm":
+        return ArcticLSTMSpeculator(config, **kw)
+    if config.method == "sum_rnn":
+        return ArcticSumRNNSpeculator(config, **kw)
+    raise ValueError(f"unknown speculator method '{config.method}' (sum_lstm, sum_rnn)")

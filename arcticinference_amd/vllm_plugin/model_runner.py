@@ -81,20 +81,17 @@ def _speculator_tp_group():
 
 
 def ArcticLSTMSpeculatorForVllm(*, vllm_config, prefix: str = ""):
-    from ..speculator import ArcticLSTMSpeculator, LSTMSpeculatorConfig
+    from ..speculator import LSTMSpeculatorConfig, lstm_family_speculator
     hf = vllm_config.model_config.hf_config
-    method = getattr(hf, "method", "sum_rnn")          # the reference's default (arctic_speculator.py:425)
-    if method != "sum_lstm":
-        # the reference also runs sum_rnn checkpoints (arctic_speculator.py:476-543); this build does not
-        raise ValueError(f"ArcticInference (MI355X build): speculator method '{method}' is not supported; only "
-                         "'sum_lstm' checkpoints (ArcticLSTMSpeculator) and ArcticMLPSpeculator load")
+    method = getattr(hf, "method", "sum_rnn")          # the reference's default (arctic_speculator.py:441)
     cfg = LSTMSpeculatorConfig(vocab_size=hf.vocab_size, input_hidden_dim=hf.input_hidden_dim, inner_dim=hf.inner_dim,
                                emb_dim=hf.emb_dim, proj_dim=hf.proj_dim, n_predict=hf.n_predict,
                                num_lookahead_tokens=hf.num_lookahead_tokens, tie_weights=hf.tie_weights,
-                               tie_lstm_embs=hf.tie_lstm_embs, scale_input=hf.scale_input, method=method)
+                               tie_lstm_embs=getattr(hf, "tie_lstm_embs", True), scale_input=hf.scale_input, method=method)
     size, rank, group = _speculator_tp_group()
-    return ArcticLSTMSpeculator(cfg, max_num_seqs=vllm_config.scheduler_config.max_num_seqs, tp_size=size, tp_rank=rank,
-                                tp_group=group)
+    # "sum_lstm" -> the LSTM kernels; "sum_rnn" -> the same head on the MLP-speculator kernels (stacked stages refused)
+    return lstm_family_speculator(cfg, max_num_seqs=vllm_config.scheduler_config.max_num_seqs, tp_size=size, tp_rank=rank,
+                                  tp_group=group)
 
 
 def ArcticMLPSpeculatorForVllm(*, vllm_config, prefix: str = ""):

@@ -597,6 +597,35 @@ def test_mlp_speculator(B, tie, scale_input, fp8):
         m.generate_proposals(ids.to(DEV), hidden.to(DEV), 4)
 
 
+@pytest.mark.parametrize("tie", [True, False])
+def test_lstm_speculator_method_sum_rnn(tie):
+    """ArcticLSTMSpeculator with method "sum_rnn" (the reference's default, arctic_speculator.py:441,691-703): the
+    Sequential-named checkpoint (`emb.{i}.0.weight`, `proj.{i}.0.weight`, `ln.{i}.0.*`) loads through the LSTM class's
+    registry name and gives the op-sequence oracle's tokens; stacked stages are refused."""
+    from arcticinference_amd.speculator import (ArcticSumRNNSpeculator, LSTMSpeculatorConfig, MLPSpeculatorConfig,
+                                                lstm_family_speculator, random_mlp_weights)
+    V, H, Ds, B = 3000, 768, 512, 9
+    ck = random_mlp_weights(MLPSpeculatorConfig(vocab_size=V, emb_dim=H, inner_dim=Ds, n_predict=3, num_lookahead_tokens=3,
+                                                tie_weights=tie, scale_input=True), seed=4, std=0.05)
+    seq = {}
+    for k, v in ck.items():          # the names the reference's nn.Sequential wrappers give the same tensors
+        parts = k.split(".")
+        seq["speculator." + (".".join(parts[:2] + ["0"] + parts[2:]) if parts[0] in ("emb", "proj", "ln") else k)] = v
+    cfg = LSTMSpeculatorConfig(vocab_size=V, input_hidden_dim=H, inner_dim=str(Ds), emb_dim=str(Ds), proj_dim=str(Ds),
+                               n_predict=3, num_lookahead_tokens=3, tie_weights=tie, scale_input=True, method="sum_rnn")
+    m = lstm_family_speculator(cfg, max_num_seqs=16, device=DEV, quantize_lm_head=False)
+    assert isinstance(m, ArcticSumRNNSpeculator)
+    m.load_weights(seq.items())
+    g = torch.Generator().manual_seed(3)
+    hidden = torch.randn(B, H, generator=g).to(torch.bfloat16)
+    ids = torch.randint(0, V, (B,), generator=g)
+    want, logits = O.mlp_generate_proposals(ck, ids, hidden, 3, 3, Ds, tie, True, fp8_head=False, return_logits=True)
+    got = m.generate_proposals(ids.to(DEV), hidden.to(DEV), 3).cpu()
+    rerun = lambda forced: O.mlp_generate_proposals(ck, ids, hidden, 3, 3, Ds, tie, True, fp8_head=False, return_logits=True,
+                                                    forced_tokens=forced)[1]
+    _check_tokens(got, want, logits, f"sum_rnn tie={tie}", ulps=1, rerun=rerun)
+
+
 def test_mlp_speculator_sharded_embedding_c9():
     """C9 (vocab_parallel_embedding.py:161-178,425-444): the MLP speculator's token embedding sharded over the TP group.
     (1) every rank's masked lookup, summed (the all-reduce), is the full table's row, bit for bit; (2) a model that is fed
