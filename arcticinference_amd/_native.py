@@ -85,6 +85,7 @@ _SIGNATURES = {
                                        c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p]),
     "aic_sc_last_stats": (c_int, [c_void_p, POINTER(c_float), POINTER(c_int64), POINTER(c_int64)]),
+    "aic_sc_last_timing": (c_int, [c_void_p, POINTER(c_float), POINTER(c_float)]),
     "aic_sc_global_tree": (c_void_p, [c_void_p]),
     "aic_sc_prompt_tree": (c_void_p, [c_void_p, c_int64]),
     "aic_reshape_and_cache_flash_bulk": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_void_p,

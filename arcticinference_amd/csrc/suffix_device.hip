@@ -14,6 +14,7 @@
 // A second one-wave-per-query kernel reduces the per-start candidates with the reference's tie
 // rules (strict >, earlier start wins; prompt tree wins ties against the global tree).
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <algorithm>
 #include <cstring>
@@ -631,6 +632,7 @@ static void release_image(aic_suffix_tree* t) {
 
 struct aic_suffix_cache {
   explicit aic_suffix_cache(int depth) : max_depth(depth), global(new aic_suffix_tree(depth)) {}
+  float last_build_us = 0.0f, last_device_us = 0.0f;   // aic_sc_last_timing
   // evicted prompt trees are destroyed by a detached-from-the-engine host thread; at most one is in flight
   std::thread reaper;
   void retire(std::unique_ptr<aic_suffix_tree> t) {
@@ -954,6 +956,7 @@ int aic_sc_speculate_batch(aic_suffix_cache* c, int n_query, const int64_t* reqs
   }
   AIC_NEED_DEVICE();
   Mirror& mir = c->mirror;
+  const auto t_begin = std::chrono::steady_clock::now();
   mir.begin();
   int rc, gdesc = -1;
   if ((rc = mir.add_tree(c->global.get(), c->pool, &gdesc)) != AIC_OK) return mir.fail_batch(rc);
@@ -991,8 +994,22 @@ int aic_sc_speculate_batch(aic_suffix_cache* c, int n_query, const int64_t* reqs
     }
     n_starts = std::max(n_starts, len);
   }
-  return mir.run(qs, pool_words, n_starts, cap, out_tokens, out_probs, out_n, out_score, out_match_len,
-                 static_cast<hipStream_t>(stream));
+  const auto t_built = std::chrono::steady_clock::now();
+  rc = mir.run(qs, pool_words, n_starts, cap, out_tokens, out_probs, out_n, out_score, out_match_len,
+               static_cast<hipStream_t>(stream));
+  const auto t_done = std::chrono::steady_clock::now();
+  c->last_build_us = std::chrono::duration<float, std::micro>(t_built - t_begin).count();
+  c->last_device_us = std::chrono::duration<float, std::micro>(t_done - t_built).count();
+  return rc;
+}
+
+// where the last aic_sc_speculate_batch spent its wall time: collecting the trees' deltas and the queries on the host,
+// then everything from the staging copy to the stream synchronisation (tools/host_profile.py)
+int aic_sc_last_timing(const aic_suffix_cache* c, float* build_us, float* device_us) {
+  AIC_REQUIRE(c, "null cache");
+  if (build_us) *build_us = c->last_build_us;
+  if (device_us) *device_us = c->last_device_us;
+  return AIC_OK;
 }
 
 int aic_sc_last_stats(const aic_suffix_cache* c, float* match_us, int64_t* mirrored_bytes, int64_t* n_nodes_total) {

@@ -149,6 +149,8 @@ int aic_sc_speculate_batch(aic_suffix_cache* c, int n_query, const int64_t* reqs
 /* device time of the last aic_sc_speculate_batch matcher launch pair in microseconds (HIP events
  * on the caller's stream), and the number of bytes mirrored host->device for it */
 int aic_sc_last_stats(const aic_suffix_cache* c, float* match_us, int64_t* mirrored_bytes, int64_t* n_nodes_total);
+/* wall time of the last aic_sc_speculate_batch: host-side delta / query collection, then staging copy .. stream sync */
+int aic_sc_last_timing(const aic_suffix_cache* c, float* build_us, float* device_us);
 aic_suffix_tree* aic_sc_global_tree(aic_suffix_cache* c);
 aic_suffix_tree* aic_sc_prompt_tree(aic_suffix_cache* c, int64_t req);
 

@@ -57,9 +57,17 @@ gc.collect()
 gc.freeze()
 pr = cProfile.Profile()
 pr.enable()
+import ctypes
+from arcticinference_amd import _native as N
+spec_build = spec_dev = 0.0
 for _ in range(steps):
     run_step()
+    b, d = ctypes.c_float(0), ctypes.c_float(0)
+    N.lib().aic_sc_last_timing(eng.suffix_cache._h, ctypes.byref(b), ctypes.byref(d))
+    spec_build += b.value
+    spec_dev += d.value
 pr.disable()
+print(f"aic_sc_speculate_batch per call: host collection {spec_build / steps:.1f} us, staging copy .. stream sync {spec_dev / steps:.1f} us")
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
 st.sort_stats("tottime").print_stats(22)
