@@ -1383,9 +1383,12 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   const int hgroups_s = num_kv_heads / hpw;              // head groups of the short launch
   const bool direct = split_lists && n_short > 0 && n_splits == 1;
   int n_splits_long = (split_lists && n_long > 0) ? pick_splits(n_long * num_kv_heads, max_seq_len, 8, 2) : 0;
-  // the long part of a mixed call is off the launch's critical path (its workgroups start first and finish at a third
-  // of the launch: per-workgroup trace, 62 short + 2 long); more than 8 token splits only lengthen every row's slot list
-  if (mixed) n_splits_long = std::min(n_splits_long, 8);
+  // the long part of a mixed call: its workgroups start first and should be gone well before the short ones end, without
+  // flooding the CUs' second slots with many short-lived workgroups.  Measured (tools/microbench.py, 4224-token contexts; long splits 2 / 4 / 8 / 16): a 32-request call (4 short splits) with one
+  // 33-token draft 163 / 114 / 97.5 / 106 us, a 64-request call (2 short splits) with five 212 / 191.7 / 197.1 / 197.2 us, with two
+  // 20-token drafts 198 / 180.7 / 183.2 / 195.9 us: twice the short part's split count — a long workgroup with half a short one's
+  // tokens — and never more than 8.
+  if (mixed) n_splits_long = std::min(n_splits_long, std::min(8, 2 * n_splits));
   auto fits = [&](int parts) { return static_cast<size_t>(parts) * rows * (kD + 2) * sizeof(float) <= workspace_bytes; };
   while (n_splits > 1 && !fits(n_splits)) --n_splits;
   while (n_splits_long > 1 && !fits(n_splits_long)) --n_splits_long;
