@@ -51,6 +51,8 @@ def fix_flash_attention_metadata(attn_metadata, logits_indices: torch.Tensor) ->
     attn_metadata.query_start_loc = torch.searchsorted(logits_indices, attn_metadata.query_start_loc.to(logits_indices.dtype),
                                                        out_int32=True)
     attn_metadata.slot_mapping = attn_metadata.slot_mapping[logits_indices]
+    if getattr(attn_metadata, "query_start_loc_cpu", None) is not None:
+        attn_metadata.query_start_loc_cpu = None      # a host mirror some metadata classes keep: stale now
     # cascade attention is not combined with SwiftKV
     attn_metadata.use_cascade = False
     for name in ("cu_prefix_query_lens", "prefix_kv_lens", "suffix_kv_lens", "prefix_scheduler_metadata"):

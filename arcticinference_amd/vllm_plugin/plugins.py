@@ -38,7 +38,16 @@ def arctic_inference_plugin() -> None:
     if _native.lib().aic_device_count() <= 0:
         logger.warning("ArcticInference (MI355X build): no HIP device visible in this process; kernels will refuse to run")
 
+    # SwiftKV: HF config type + model class (plugins.py:86-98); the class is resolved from its "module:Class" string on
+    # first use, so vLLM's model zoo is not imported here
+    from transformers import AutoConfig
+    from ..swiftkv_config import LlamaSwiftKVConfig
+    try:
+        AutoConfig.register("llama_swiftkv", LlamaSwiftKVConfig)
+    except ValueError:          # already registered (the plugin is loaded once per process, tests load it repeatedly)
+        pass
     from vllm import ModelRegistry
+    ModelRegistry.register_model("LlamaSwiftKVForCausalLM", "arctic_inference.vllm.swiftkv:LlamaSwiftKVForCausalLM")
     ModelRegistry.register_model("ArcticMLPSpeculatorPreTrainedModel",
                                  "arcticinference_amd.vllm_plugin.model_runner:ArcticMLPSpeculatorForVllm")
     ModelRegistry.register_model("ArcticLSTMSpeculatorPreTrainedModel",

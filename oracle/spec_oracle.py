@@ -335,3 +335,65 @@ def swiftkv_select(hidden_states, residual, positions, k_states, v_states, query
     new_slots = slot_mapping[logits_indices]
     sel = tuple(t.index_select(0, logits_indices) for t in (hidden_states, residual, positions, k_states, v_states))
     return sel, new_qsl, new_slots
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SwiftKV Llama, whole model (/root/reference/arctic_inference/vllm/swiftkv/llama_swiftkv.py:219-321, 690-712): logits of
+# the LAST position of one sequence, recomputed from scratch in fp32.  Layers < n_kv are plain Llama layers over every
+# token; the later layers' K / V of every token come from norm_swiftkv(residual stream after layer n_kv - 1); only the
+# last token runs through the later layers (query from q_proj_swiftkv).  Rotary: neox style over the whole head.
+# ---------------------------------------------------------------------------------------------------------------------
+def swiftkv_llama_last_logits(w: dict, tokens, n_layers: int, n_kv: int, n_heads: int, n_kv_heads: int, head_dim: int,
+                              rope_theta: float = 10000.0, eps: float = 1e-5) -> torch.Tensor:
+    f = lambda name: w[name].float()
+    T = len(tokens)
+    pos = torch.arange(T, dtype=torch.float32)
+
+    def rms(x, name):
+        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps) * f(name)
+
+    def rope(x, positions):                      # x [n, heads * D]
+        n = x.shape[0]
+        h = x.view(n, -1, head_dim)
+        half = head_dim // 2
+        inv = 1.0 / (rope_theta ** (torch.arange(0, half, dtype=torch.float32) / half))
+        ang = positions[:, None] * inv[None, :]
+        cos, sin = ang.cos()[:, None, :], ang.sin()[:, None, :]
+        a, b = h[..., :half], h[..., half:]
+        return torch.cat([a * cos - b * sin, b * cos + a * sin], dim=-1).reshape(n, -1)
+
+    def attend(q, k, v, q_pos):                  # q [nq, Hq*D] at absolute positions q_pos; k, v [T, Hkv*D]
+        G = n_heads // n_kv_heads
+        qh = q.view(-1, n_heads, head_dim)
+        kh = k.view(-1, n_kv_heads, head_dim).repeat_interleave(G, dim=1)
+        vh = v.view(-1, n_kv_heads, head_dim).repeat_interleave(G, dim=1)
+        s = torch.einsum("qhd,khd->hqk", qh, kh) * head_dim ** -0.5
+        mask = torch.arange(k.shape[0])[None, :] > q_pos[:, None]
+        s = s.masked_fill(mask[None], float("-inf"))
+        return torch.einsum("hqk,khd->qhd", torch.softmax(s, dim=-1), vh).reshape(-1, n_heads * head_dim)
+
+    def mlp(x, pre):
+        return (torch.nn.functional.silu(x @ f(pre + "gate_proj.weight").T) * (x @ f(pre + "up_proj.weight").T)) @ \
+            f(pre + "down_proj.weight").T
+
+    x = f("model.embed_tokens.weight")[torch.as_tensor(tokens)]
+    for i in range(n_kv):
+        pre = f"model.layers.{i}."
+        h = rms(x, pre + "input_layernorm.weight")
+        q = rope(h @ f(pre + "self_attn.q_proj.weight").T, pos)
+        k = rope(h @ f(pre + "self_attn.k_proj.weight").T, pos)
+        v = h @ f(pre + "self_attn.v_proj.weight").T
+        x = x + attend(q, k, v, pos.long()) @ f(pre + "self_attn.o_proj.weight").T
+        x = x + mlp(rms(x, pre + "post_attention_layernorm.weight"), pre + "mlp.")
+    swift = rms(x, "model.norm_swiftkv.weight")
+    last = x[-1:]
+    last_pos = pos[-1:]
+    for i in range(n_kv, n_layers):
+        pre = f"model.layers.{i}."
+        k = rope(swift @ f(pre + "self_attn.k_proj_swiftkv.weight").T, pos)
+        v = swift @ f(pre + "self_attn.v_proj_swiftkv.weight").T
+        h = rms(last, pre + "input_layernorm.weight")
+        q = rope(h @ f(pre + "self_attn.q_proj_swiftkv.weight").T, last_pos)
+        last = last + attend(q, k, v, last_pos.long()) @ f(pre + "self_attn.o_proj.weight").T
+        last = last + mlp(rms(last, pre + "post_attention_layernorm.weight"), pre + "mlp.")
+    return (rms(last, "model.norm.weight") @ f("lm_head.weight").T)[0]
