@@ -110,9 +110,10 @@ __device__ __forceinline__ int v_tile_off(int t, int ch) {
 // log2 e, v_exp_f32 is base 2).  Masking runs only on tiles that touch the causal edge or the end of the
 // range, and the O rescale only when some row's maximum moved: at 33-token drafts this VALU work, not HBM,
 // bounds the long-draft kernel.  Produces P as bf16 head + tail fragments (B operand of O^T = V^T P^T).
+template <int DT>
 __device__ __forceinline__ void softmax_tile(const f32x4& s0, const f32x4& s1, bool need_mask, bool row_ok, int tt,
                                              int g, int t_end, int limit, float scale_log2, float& m_run,
-                                             float& l_run, f32x4 (&o)[8], bf16x8& pf, bf16x8& pl) {
+                                             float& l_run, f32x4 (&o)[DT], bf16x8& pf, bf16x8& pl) {
   float sc[8];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -151,7 +152,7 @@ __device__ __forceinline__ void softmax_tile(const f32x4& s0, const f32x4& s1, b
   m_run = m_new;
   if (!__all(alpha == 1.0f)) {
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) o[dt] *= alpha;
+    for (int dt = 0; dt < DT; ++dt) o[dt] *= alpha;
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -279,10 +280,10 @@ constexpr float kLn2 = 0.6931471805599453f;
 // KV8: the cache holds OCP e4m3 bytes (A16 writes them); tiles are dequantised to bf16 in registers (exact),
 // k_scale folds into the soft-max scale and v_scale into the output, so no per-element scaling is needed.
 // One 16-byte K load then covers the k-slots of TWO MFMA steps, and the Q fragments use the same slot map.
-template <int MTQ, int NW>
+template <int MTQ, int NW, int HD = kD>
 struct ShortLds {
-  // per wave: one 32-token V tile (8 KiB); reused at the end for the cross-wave merge
-  static constexpr int kMergeU4 = (8 * MTQ * 16 + 3 * MTQ * 16 * kD) / 4;
+  // per wave: one 32-token V tile (8 KiB; 4 KiB of it used with 128-byte rows); reused at the end for the cross-wave merge
+  static constexpr int kMergeU4 = (8 * MTQ * 16 + 3 * MTQ * 16 * HD) / 4;
   static constexpr int kU4 = NW * kTile * 16 > kMergeU4 ? NW * kTile * 16 : kMergeU4;
 };
 
@@ -293,8 +294,14 @@ struct ShortLds {
 // Smaller HPW trades that for more workgroups per request WITHOUT cross-workgroup partials: with 64 requests x 8 kv heads,
 // HPW = 2 gives 256 workgroups whose waves stream exactly what the HPW = 4 / two-split form streamed per wave, but the two
 // halves of a head meet in LDS and the finished row goes straight to `out` — no partial write, no combine launch.
-template <int MTQ, int HPW, bool KV8, int NW>
+// HD = head size: 128, or 64 with a bf16 cache (gpt-oss).  A 64-wide bf16 head is a 128-byte token row like a 128-wide fp8
+// one: K and V are fetched with the fp8 form's lane mapping (two 16-byte K loads per token group, four V loads per tile),
+// used as they are (no conversion), with two k-steps per score MFMA chain and four 16-wide output tiles.
+template <int MTQ, int HPW, bool KV8, int NW, int HD = kD>
 __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_lds_raw, const int bx, const int by) {
+  static_assert(HD == 128 || (HD == 64 && !KV8), "head size 128, or 64 with a bf16 cache");
+  constexpr bool ROW128 = KV8 || HD == 64;   // bytes of a token row of one head: 128 (else 256)
+  constexpr int DT = HD / 16;                // 16-wide tiles of the output's head dimension
   constexpr bool WH = HPW == NW;
   constexpr int R = NW / HPW;   // token ranges (waves) per head inside the workgroup
   static_assert(NW % HPW == 0, "waves must divide evenly over the heads of a workgroup");
@@ -331,7 +338,7 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
   const int t_begin = part * tiles_per_part * kTile;
   const int t_end = min(ctx, t_begin + tiles_per_part * kTile);
 
-  const int64_t kv_row = static_cast<int64_t>(Hkv) * kD;  // elements between consecutive tokens of a page
+  const int64_t kv_row = static_cast<int64_t>(Hkv) * HD;  // elements between consecutive tokens of a page
   const_i32_ptr btab = (const_i32_ptr)(P.block_table + static_cast<int64_t>(req) * P.max_blocks);
   const int bs = P.block_size;  // multiple of 16: a 16-token group never straddles two pages
   const float scale_log2 = P.sm_scale * kLog2e * (KV8 ? *P.k_scale : 1.0f);
@@ -351,20 +358,20 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
     const int rc = min(rr, n_rows - 1);
     const int pos = rc / G, gq = rc - pos * G;
     row_pos[mt] = pos;
-    const uint16_t* qrow = P.q + static_cast<int64_t>(q0 + pos) * P.q_stride + static_cast<int64_t>(h * G + gq) * kD;
+    const uint16_t* qrow = P.q + static_cast<int64_t>(q0 + pos) * P.q_stride + static_cast<int64_t>(h * G + gq) * HD;
 #pragma unroll
-    for (int s = 0; s < 4; ++s)  // k-slot (s, g, j) -> d = 32 s + 8 g + j (bf16) | 64 (s/2) + 16 g + 8 (s%2) + j (fp8)
+    for (int s = 0; s < HD / 32; ++s)  // k-slot (s, g, j) -> d = 32 s + 8 g + j (bf16) | 64 (s/2) + 16 g + 8 (s%2) + j (fp8)
       qf[mt][s] = *reinterpret_cast<const uint4*>(qrow + (KV8 ? 64 * (s >> 1) + 16 * g + 8 * (s & 1) : 32 * s + 8 * g));
   }
 
   float m_run[MTQ], l_run[MTQ];
-  f32x4 o_acc[MTQ][8];
+  f32x4 o_acc[MTQ][DT];
 #pragma unroll
   for (int mt = 0; mt < MTQ; ++mt) {
     m_run[mt] = -INFINITY;
     l_run[mt] = 0.0f;
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) o_acc[mt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < DT; ++dt) o_acc[mt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
   char* vt = reinterpret_cast<char*>(v_lds[wave]);
@@ -382,8 +389,8 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
     tp.first0 = min(tt, last_group);
     tp.first1 = min(tt + 16, last_group);
     const int b0 = btab[tp.first0 / bs], b1 = btab[tp.first1 / bs];
-    tp.base0 = static_cast<int64_t>(b0) * P.block_stride + static_cast<int64_t>(tp.first0 % bs) * kv_row + h * kD;
-    tp.base1 = static_cast<int64_t>(b1) * P.block_stride + static_cast<int64_t>(tp.first1 % bs) * kv_row + h * kD;
+    tp.base0 = static_cast<int64_t>(b0) * P.block_stride + static_cast<int64_t>(tp.first0 % bs) * kv_row + h * HD;
+    tp.base1 = static_cast<int64_t>(b1) * P.block_stride + static_cast<int64_t>(tp.first1 % bs) * kv_row + h * HD;
     return tp;
   };
 
@@ -392,7 +399,7 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
   // scratch memory by the compiler whenever 3 waves per SIMD are requested.
   uint4 k00, k01, k02, k03, k10, k11, k12, k13;  // k<th><s>
   uint4 v0, v1, v2, v3, v4, v5, v6, v7;          // v<iv>
-  if (KV8) k02 = k03 = k12 = k13 = v4 = v5 = v6 = v7 = make_uint4(0, 0, 0, 0);
+  if (ROW128) k02 = k03 = k12 = k13 = v4 = v5 = v6 = v7 = make_uint4(0, 0, 0, 0);
 #define AIC_LOAD_K(tt_, tp_)                                                                                   \
   {                                                                                                            \
     const int off0_ = min((tt_) + c16, ctx - 1) - (tp_).first0;                                                \
@@ -403,7 +410,7 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
     k01 = ld_kv16(kp0_ + 64);                                                          \
     k10 = ld_kv16(kp1_);                                                               \
     k11 = ld_kv16(kp1_ + 64);                                                          \
-    if (!KV8) {                                                                                                \
+    if (!ROW128) {                                                                                             \
       k02 = ld_kv16(kp0_ + 128);                                                       \
       k03 = ld_kv16(kp0_ + 192);                                                       \
       k12 = ld_kv16(kp1_ + 128);                                                       \
@@ -412,8 +419,8 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
   }
   // bf16: instruction iv moves tokens 4 iv + g, 16-byte chunk c16;  fp8: tokens 8 iv + lane/8, chunk lane%8
 #define AIC_V_ADDR(tt_, tp_, iv_)                                                                              \
-  (KV8 ? vc + ((iv_) >= 2 ? (tp_).base1 : (tp_).base0) +                                                        \
-             static_cast<int64_t>(min((tt_) + 8 * (iv_) + (lane >> 3), ctx - 1) - ((iv_) >= 2 ? (tp_).first1 : (tp_).first0)) * kv_row + 16 * (lane & 7) \
+  (ROW128 ? vc + (((iv_) >= 2 ? (tp_).base1 : (tp_).base0) +                                                    \
+             static_cast<int64_t>(min((tt_) + 8 * (iv_) + (lane >> 3), ctx - 1) - ((iv_) >= 2 ? (tp_).first1 : (tp_).first0)) * kv_row) * ES + 16 * (lane & 7) \
        : vc + (((iv_) >= 4 ? (tp_).base1 : (tp_).base0) +                                                       \
                static_cast<int64_t>(min((tt_) + 4 * (iv_) + g, ctx - 1) - ((iv_) >= 4 ? (tp_).first1 : (tp_).first0)) * kv_row) * 2 + 16 * c16)
 #define AIC_LOAD_V(tt_, tp_)                                                                                   \
@@ -422,7 +429,7 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
     v1 = ld_kv16(AIC_V_ADDR(tt_, tp_, 1));                                             \
     v2 = ld_kv16(AIC_V_ADDR(tt_, tp_, 2));                                             \
     v3 = ld_kv16(AIC_V_ADDR(tt_, tp_, 3));                                             \
-    if (!KV8) {                                                                                                \
+    if (!ROW128) {                                                                                             \
       v4 = ld_kv16(AIC_V_ADDR(tt_, tp_, 4));                                           \
       v5 = ld_kv16(AIC_V_ADDR(tt_, tp_, 5));                                           \
       v6 = ld_kv16(AIC_V_ADDR(tt_, tp_, 6));                                           \
@@ -436,6 +443,8 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
       *reinterpret_cast<bf16x8*>(vt + v_tile_off(tok_, ch_)) = fp8x8_to_bf16x8(reg_.x, reg_.y);                \
       *reinterpret_cast<bf16x8*>(vt + v_tile_off(tok_, ch_ + 1)) = fp8x8_to_bf16x8(reg_.z, reg_.w);            \
     }                                                                                                          \
+  } else if (HD == 64) {                                                                                       \
+    if ((iv_) < 4) *reinterpret_cast<uint4*>(vt + tile_off<64>(8 * (iv_) + (lane >> 3), lane & 7)) = reg_;     \
   } else {                                                                                                     \
     *reinterpret_cast<uint4*>(vt + v_tile_off(4 * (iv_) + g, c16)) = reg_;                                     \
   }
@@ -474,6 +483,9 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
           AIC_QK(a0, fp8x8_to_bf16x8(k01.x, k01.y), 2) AIC_QK(a0, fp8x8_to_bf16x8(k01.z, k01.w), 3)
           AIC_QK(a1, fp8x8_to_bf16x8(k10.x, k10.y), 0) AIC_QK(a1, fp8x8_to_bf16x8(k10.z, k10.w), 1)
           AIC_QK(a1, fp8x8_to_bf16x8(k11.x, k11.y), 2) AIC_QK(a1, fp8x8_to_bf16x8(k11.z, k11.w), 3)
+        } else if (HD == 64) {      // two k-steps: d = 8 g + j and 32 + 8 g + j
+          AIC_QK(a0, AIC_B16(k00), 0) AIC_QK(a0, AIC_B16(k01), 1)
+          AIC_QK(a1, AIC_B16(k10), 0) AIC_QK(a1, AIC_B16(k11), 1)
         } else {
           AIC_QK(a0, AIC_B16(k00), 0) AIC_QK(a0, AIC_B16(k01), 1) AIC_QK(a0, AIC_B16(k02), 2) AIC_QK(a0, AIC_B16(k03), 3)
           AIC_QK(a1, AIC_B16(k10), 0) AIC_QK(a1, AIC_B16(k11), 1) AIC_QK(a1, AIC_B16(k12), 2) AIC_QK(a1, AIC_B16(k13), 3)
@@ -491,7 +503,7 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
       const bool need_mask = tn > t_end || tn > ctx - q_len + 1;  // the tile reaches the causal edge / range end
 #pragma unroll
       for (int mt = 0; mt < MTQ; ++mt) {
-        softmax_tile(st[mt][0], st[mt][1], need_mask, row_ok[mt], tt, g, t_end, ctx - q_len + row_pos[mt], scale_log2,
+        softmax_tile<DT>(st[mt][0], st[mt][1], need_mask, row_ok[mt], tt, g, t_end, ctx - q_len + row_pos[mt], scale_log2,
                      m_run[mt], l_run[mt], o_acc[mt], pfrag[mt], pfrag_lo[mt]);
       }
 
@@ -499,10 +511,10 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
       {
         const int q4 = c16 >> 2, p4 = c16 & 3;
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
+        for (int dt = 0; dt < DT; ++dt) {
           // lane 4q+p of a 16-lane group supplies row q of the block, columns 4p..4p+3 (8 bytes)
-          const char* a_lo = vt + v_tile_off(4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
-          const char* a_hi = vt + v_tile_off(16 + 4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
+          const char* a_lo = vt + tile_off<HD>(4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
+          const char* a_hi = vt + tile_off<HD>(16 + 4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(a_lo)));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -526,10 +538,10 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
 #undef AIC_STORE_V
 
   // finished rows (direct mode): normalise, round to bf16, 8 bytes per lane and 16-wide d tile
-  auto store_final = [&](int mt, const f32x4 (&o)[8], float inv_l, int64_t tok, int hq) {
-    uint16_t* op = P.out + tok * P.out_stride + static_cast<int64_t>(hq) * kD + 4 * g;
+  auto store_final = [&](int mt, const f32x4 (&o)[DT], float inv_l, int64_t tok, int hq) {
+    uint16_t* op = P.out + tok * P.out_stride + static_cast<int64_t>(hq) * HD + 4 * g;
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
+    for (int dt = 0; dt < DT; ++dt) {
       const uint32_t lo = static_cast<uint32_t>(f32_to_bf16(o[dt][0] * inv_l)) | (static_cast<uint32_t>(f32_to_bf16(o[dt][1] * inv_l)) << 16);
       const uint32_t hi = static_cast<uint32_t>(f32_to_bf16(o[dt][2] * inv_l)) | (static_cast<uint32_t>(f32_to_bf16(o[dt][3] * inv_l)) << 16);
       *reinterpret_cast<uint2*>(op + dt * 16) = make_uint2(lo, hi);
@@ -554,9 +566,9 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
         if (g == 0 && P.mark_final) mark_row_final(grow);
         continue;
       }
-      float* op = P.ws_o + (static_cast<int64_t>(by) * P.total_rows + grow) * kD + 4 * g;
+      float* op = P.ws_o + (static_cast<int64_t>(by) * P.total_rows + grow) * HD + 4 * g;
 #pragma unroll
-      for (int dt = 0; dt < 8; ++dt)
+      for (int dt = 0; dt < DT; ++dt)
         *reinterpret_cast<float4*>(op + dt * 16) =
             make_float4(o_acc[mt][dt][0] * out_scale, o_acc[mt][dt][1] * out_scale, o_acc[mt][dt][2] * out_scale,
                         o_acc[mt][dt][3] * out_scale);
@@ -574,7 +586,7 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
   __syncthreads();  // every wave is done with its V tile: the LDS is free
   float* xm = reinterpret_cast<float*>(v_lds_raw);  // [NW waves][MTQ][16 rows] running max
   float* xl = xm + NW * MTQ * 16;                   // [NW][MTQ][16] running sum
-  float* xo = xl + NW * MTQ * 16;                   // [NW - HPW non-leader waves][MTQ][16 rows][128] rescaled O
+  float* xo = xl + NW * MTQ * 16;                   // [NW - HPW non-leader waves][MTQ][16 rows][HD] rescaled O
 #pragma unroll
   for (int mt = 0; mt < MTQ; ++mt)
     if (g == 0) {
@@ -602,8 +614,8 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
 #pragma unroll
     for (int mt = 0; mt < MTQ; ++mt)
 #pragma unroll
-      for (int dt = 0; dt < 8; ++dt) {
-        float* dst = xo + ((static_cast<size_t>(nl) * MTQ + mt) * 16 + c16) * kD + dt * 16 + 4 * g;
+      for (int dt = 0; dt < DT; ++dt) {
+        float* dst = xo + ((static_cast<size_t>(nl) * MTQ + mt) * 16 + c16) * HD + dt * 16 + 4 * g;
         *reinterpret_cast<float4*>(dst) = make_float4(o_acc[mt][dt][0] * scale_w[mt], o_acc[mt][dt][1] * scale_w[mt],
                                                        o_acc[mt][dt][2] * scale_w[mt], o_acc[mt][dt][3] * scale_w[mt]);
       }
@@ -617,14 +629,14 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
     const int rr = row0 + mt * 16 + c16;
     const int pos = rr / G, gq = rr - pos * G;
     const int64_t grow = static_cast<int64_t>(q0 + pos) * Hq + h * G + gq;
-    f32x4 acc[8];
+    f32x4 acc[DT];
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
+    for (int dt = 0; dt < DT; ++dt) {
       acc[dt] = f32x4{o_acc[mt][dt][0] * scale_w[mt], o_acc[mt][dt][1] * scale_w[mt], o_acc[mt][dt][2] * scale_w[mt],
                       o_acc[mt][dt][3] * scale_w[mt]};
       for (int w = 0; w < R - 1; ++w) {
         const float4 o = *reinterpret_cast<const float4*>(
-            xo + ((static_cast<size_t>(head_local * (R - 1) + w) * MTQ + mt) * 16 + c16) * kD + dt * 16 + 4 * g);
+            xo + ((static_cast<size_t>(head_local * (R - 1) + w) * MTQ + mt) * 16 + c16) * HD + dt * 16 + 4 * g);
         acc[dt][0] += o.x;
         acc[dt][1] += o.y;
         acc[dt][2] += o.z;
@@ -636,9 +648,9 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
       if (g == 0 && P.mark_final) mark_row_final(grow);
       continue;
     }
-    float* op = P.ws_o + (static_cast<int64_t>(bpart) * P.total_rows + grow) * kD + 4 * g;
+    float* op = P.ws_o + (static_cast<int64_t>(bpart) * P.total_rows + grow) * HD + 4 * g;
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
       *reinterpret_cast<float4*>(op + dt * 16) = make_float4(acc[dt][0], acc[dt][1], acc[dt][2], acc[dt][3]);
     if (g == 0) {
       float* mp = P.ws_ml + (static_cast<int64_t>(bpart) * P.total_rows + grow) * 2;
@@ -654,26 +666,26 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
 // or a k = 3 draft (<= 16 rows with Hq/Hkv <= 4); suffix drafts of 4-7 tokens (17-32 rows; 46 % of all suffix drafts in
 // the r02 bench, `bench.py --qlen-hist`) used to go through the shared-tile long-draft body, where a request costs ~6 us
 // per layer whatever its length, against ~2.7 us for a workgroup of this streaming body.
-template <int HPW, bool KV8, int NW>
+template <int HPW, bool KV8, int NW, int HD = kD>
 __device__ __forceinline__ void verify_attn_body_dual(const AttnParams& P, uint4* v_lds_raw, const int bx, const int by) {
   if (bx >= P.n_items) return;             // m_groups == 1: item == bx
   const int ridx = bx / (P.num_kv_heads / HPW);
   const int req = __builtin_amdgcn_readfirstlane(P.req_list ? P.req_list[ridx] : ridx);
   const int q_len = __builtin_amdgcn_readfirstlane(P.query_start_loc[req + 1] - P.query_start_loc[req]);
   if (q_len * (P.num_q_heads / P.num_kv_heads) <= 16)
-    verify_attn_body<1, HPW, KV8, NW>(P, v_lds_raw, bx, by);
+    verify_attn_body<1, HPW, KV8, NW, HD>(P, v_lds_raw, bx, by);
   else
-    verify_attn_body<2, HPW, KV8, NW>(P, v_lds_raw, bx, by);
+    verify_attn_body<2, HPW, KV8, NW, HD>(P, v_lds_raw, bx, by);
 }
 
 // MTQ = 0: the per-workgroup choice above
-template <int MTQ, int HPW, bool KV8, int NW = 4>
+template <int MTQ, int HPW, bool KV8, int NW = 4, int HD = kD>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((MTQ == 1 && NW == 4) ? 3 : 2, (MTQ == 1 && NW == 4) ? 3 : 2))) verify_attn_kernel(AttnParams P) {
-  __shared__ uint4 v_lds_raw[ShortLds<MTQ == 0 ? 2 : MTQ, NW>::kU4];
+  __shared__ uint4 v_lds_raw[ShortLds<MTQ == 0 ? 2 : MTQ, NW, HD>::kU4];
   if constexpr (MTQ == 0)
-    verify_attn_body_dual<HPW, KV8, NW>(P, v_lds_raw, blockIdx.x, blockIdx.y);
+    verify_attn_body_dual<HPW, KV8, NW, HD>(P, v_lds_raw, blockIdx.x, blockIdx.y);
   else
-    verify_attn_body<MTQ, HPW, KV8, NW>(P, v_lds_raw, blockIdx.x, blockIdx.y);
+    verify_attn_body<MTQ, HPW, KV8, NW, HD>(P, v_lds_raw, blockIdx.x, blockIdx.y);
 }
 
 // One 32-token KV tile (K and V images in LDS at kb / vb, v_tile_off layout) against the NT row tiles of a wave
@@ -820,8 +832,8 @@ constexpr int kLong4LdsU4 = kLongRing * 2 * kTile * 16;
 // quarter of the NEXT tile into one of two bf16 images (tile_off layout, exact: every e4m3 value is a bf16 value)
 // while the current one is being consumed, so the compute code is the bf16 one and there is still one barrier per
 // tile.  k_scale folds into the soft-max scale, v_scale into the output.
-// D = 64 (bf16 cache only): 128-byte rows, i.e. the DMA geometry of the fp8 case without the conversion; this body
-// then serves every request of a call (the hand-scheduled short body is D = 128 only).
+// D = 64 (bf16 cache only): 128-byte rows, i.e. the DMA geometry of the fp8 case without the conversion (long drafts of a
+// head-size-64 model; requests of up to 32 rows take the streaming body's HD = 64 form).
 template <bool KV8, int D>
 __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint4* lds, const int bx, const int by, const int bz) {
   static_assert(D == 128 || (D == 64 && !KV8), "head size 128, or 64 with a bf16 cache");
@@ -1314,53 +1326,7 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   }
   AIC_NEED_DEVICE();
 
-  if (head_size == 64) {
-    // the secondary head size (gpt-oss): every request of the call takes the shared-tile body (one kv head and one
-    // token range per workgroup, up to 192 rows), whatever its query length; then the combine kernel
-    const size_t rows64 = static_cast<size_t>(num_tokens) * num_q_heads;
-    const int items = batch * num_kv_heads;
-    int splits = pick_splits(items, max_seq_len, 4, 2);
-    auto fits64 = [&](int parts) { return static_cast<size_t>(parts) * rows64 * (64 + 2) * sizeof(float) <= workspace_bytes; };
-    while (splits > 1 && !fits64(splits)) --splits;
-    AIC_REQUIRE(fits64(splits), "workspace too small (%zu bytes)", workspace_bytes);
-    AttnParams P;
-    P.q = static_cast<const uint16_t*>(q);
-    P.k_cache = static_cast<const uint16_t*>(k_cache);
-    P.v_cache = static_cast<const uint16_t*>(v_cache);
-    P.block_table = block_table;
-    P.seq_lens = seq_lens;
-    P.query_start_loc = query_start_loc;
-    P.ws_o = static_cast<float*>(workspace);
-    P.ws_ml = P.ws_o + static_cast<size_t>(splits) * rows64 * 64;
-    P.q_stride = q_stride;
-    P.block_stride = block_stride;
-    P.max_blocks = max_blocks_per_seq;
-    P.num_q_heads = num_q_heads;
-    P.num_kv_heads = num_kv_heads;
-    P.block_size = block_size;
-    P.n_splits = splits;
-    P.n_parts_total = splits;
-    P.total_rows = static_cast<int>(rows64);
-    P.m_groups = 1;
-    P.n_items = items;
-    P.sm_scale = sm_scale;
-    P.req_list = nullptr;
-    P.k_scale = P.v_scale = nullptr;
-    P.dbg = 0;
-    P.trace = nullptr;
-  P.trace = nullptr;
-    hipStream_t s64 = static_cast<hipStream_t>(stream);
-    const int rows_per_wg = 4 * kLongTilesPerWave * 16;
-    const int max_rows64 = max_q_len * (num_q_heads / num_kv_heads);
-    dim3 grid(static_cast<unsigned>(items), static_cast<unsigned>(splits), static_cast<unsigned>((max_rows64 + rows_per_wg - 1) / rows_per_wg));
-    hipLaunchKernelGGL((verify_attn_long4_kernel<false, 64>), grid, dim3(256), 0, s64, P);
-    int rc64;
-    if ((rc64 = launch_status("verify_attn_long4_kernel<64>")) != AIC_OK) return rc64;
-    hipLaunchKernelGGL(verify_attn_combine_kernel<64>, dim3(static_cast<unsigned>((rows64 + 3) / 4)), dim3(256), 0, s64, P.ws_o,
-                       P.ws_ml, splits, static_cast<int>(rows64), num_q_heads, static_cast<uint16_t*>(out), out_stride);
-    return launch_status("verify_attn_combine_kernel<64>");
-  }
-
+  const bool d64 = head_size == 64;   // the secondary head size (gpt-oss; bf16 cache only)
   const int G = num_q_heads / num_kv_heads;
   const int max_rows = max_q_len * G;
   const bool wave_heads = num_kv_heads % 4 == 0;
@@ -1389,7 +1355,7 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   // 20-token drafts 198 / 180.7 / 183.2 / 195.9 us: twice the short part's split count — a long workgroup with half a short one's
   // tokens — and never more than 8.
   if (mixed) n_splits_long = std::min(n_splits_long, std::min(8, 2 * n_splits));
-  auto fits = [&](int parts) { return static_cast<size_t>(parts) * rows * (kD + 2) * sizeof(float) <= workspace_bytes; };
+  auto fits = [&](int parts) { return static_cast<size_t>(parts) * rows * (head_size + 2) * sizeof(float) <= workspace_bytes; };
   while (n_splits > 1 && !fits(n_splits)) --n_splits;
   while (n_splits_long > 1 && !fits(n_splits_long)) --n_splits_long;
   AIC_REQUIRE(fits(n_splits), "workspace too small (%zu bytes)", workspace_bytes);
@@ -1403,7 +1369,7 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   P.seq_lens = seq_lens;
   P.query_start_loc = query_start_loc;
   P.ws_o = static_cast<float*>(workspace);
-  P.ws_ml = P.ws_o + static_cast<size_t>(n_parts_total) * rows * kD;
+  P.ws_ml = P.ws_o + static_cast<size_t>(n_parts_total) * rows * head_size;
   P.q_stride = q_stride;
   P.block_stride = block_stride;
   P.max_blocks = max_blocks_per_seq;
@@ -1429,7 +1395,9 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   // short / generic kernel for (row tiles, heads per workgroup, cache dtype)
   auto launch_short = [&](int mtq_, int hpw_, dim3 grid_) {
 #define AIC_SHORT(MTQ_, HPW_)                                                                  \
-  if (kv8)                                                                                     \
+  if (d64)                                                                                     \
+    hipLaunchKernelGGL((verify_attn_kernel<MTQ_, HPW_, false, 4, 64>), grid_, dim3(256), 0, s, P); \
+  else if (kv8)                                                                                \
     hipLaunchKernelGGL((verify_attn_kernel<MTQ_, HPW_, true>), grid_, dim3(256), 0, s, P);     \
   else                                                                                         \
     hipLaunchKernelGGL((verify_attn_kernel<MTQ_, HPW_, false>), grid_, dim3(256), 0, s, P);
@@ -1467,7 +1435,7 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
     // one launch for both kinds of request when every workgroup of it can be resident at once (two per CU).  (Letting
     // the long part take the whole chip first — 2 workgroups per CU, the short ones dispatched as those retire — was
     // measured and is worse: 59 short + 5 long 214 us against 206 us, and the bench's real mix 267 us against 182 us.)
-    bool pair = n_short > 0 && n_long > 0;
+    bool pair = n_short > 0 && n_long > 0 && !d64;   // (the one-grid form is instantiated for head size 128)
     if (pair) {
       const int room = 2 * cu_count() - short_wg;
       const int per_split = n_long * num_kv_heads * long_z;
@@ -1519,7 +1487,9 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
       const int per_block_rows = 4 * kLongTilesPerWave * 16;
       PL.n_splits = n_splits_long;
       dim3 grid(static_cast<unsigned>(n_long * num_kv_heads), n_splits_long, (max_rows + per_block_rows - 1) / per_block_rows);
-      if (kv8)
+      if (d64)
+        hipLaunchKernelGGL((verify_attn_long4_kernel<false, 64>), grid, dim3(256), 0, overlap ? side->stream : s, PL);
+      else if (kv8)
         hipLaunchKernelGGL(verify_attn_long4_kernel<true>, grid, dim3(256), 0, overlap ? side->stream : s, PL);
       else
         hipLaunchKernelGGL(verify_attn_long4_kernel<false>, grid, dim3(256), 0, overlap ? side->stream : s, PL);
@@ -1540,8 +1510,12 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   }
   if ((rc = launch_status("verify_attn_kernel")) != AIC_OK) return rc;
   if (P.direct && !P.mark_final) return AIC_OK;   // every row of the call is already final: no combine launch
-  hipLaunchKernelGGL(verify_attn_combine_kernel<128>, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s, P.ws_o,
-                     P.ws_ml, n_parts_total, static_cast<int>(rows), num_q_heads, static_cast<uint16_t*>(out), out_stride);
+  if (d64)
+    hipLaunchKernelGGL(verify_attn_combine_kernel<64>, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s, P.ws_o,
+                       P.ws_ml, n_parts_total, static_cast<int>(rows), num_q_heads, static_cast<uint16_t*>(out), out_stride);
+  else
+    hipLaunchKernelGGL(verify_attn_combine_kernel<128>, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s, P.ws_o,
+                       P.ws_ml, n_parts_total, static_cast<int>(rows), num_q_heads, static_cast<uint16_t*>(out), out_stride);
   return launch_status("verify_attn_combine_kernel");
 }
 

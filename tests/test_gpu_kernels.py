@@ -315,20 +315,21 @@ def test_verify_attention_head_size_64(cfg):
         assert torch.allclose(got.float().cpu(), want, atol=1e-3, rtol=2 ** -8), (extra, (got.float().cpu() - want).abs().max())
 
 
-@pytest.mark.parametrize("seed", list(range(12)))
+@pytest.mark.parametrize("seed", list(range(16)))
 def test_verify_attention_random_shapes(seed):
     """Seeded random batches over the head geometries the path serves (group size 1 / 2 / 4 / 8, 1 / 2 / 4 / 8 kv heads per
     rank), query lengths 1..33 (row counts on both sides of the 16- and 32-row boundaries of the short body and of the
     192-row group of the long one), contexts from q_len itself to a few thousand tokens, block sizes 16 / 32 / 64, bf16 and
     fp8 caches, with and without the host-side partition: all against the fp32 oracle, 1e-3."""
     rng = np.random.default_rng(1000 + seed)
-    Hkv, G = [(1, 4), (8, 4), (4, 2), (2, 1), (1, 8), (2, 8), (8, 1), (4, 4), (2, 4), (1, 1), (4, 8), (8, 8)][seed]
-    Hq, D = Hkv * G, 128
+    Hkv, G = [(1, 4), (8, 4), (4, 2), (2, 1), (1, 8), (2, 8), (8, 1), (4, 4), (2, 4), (1, 1), (4, 8), (8, 8), (8, 8), (1, 8),
+              (2, 4), (8, 8)][seed]
+    fp8 = bool(seed % 3 == 2)
+    Hq, D = Hkv * G, (64 if (seed % 4 == 3 and not fp8) else 128)      # head size 64 (bf16 cache only) in a quarter of the cases
     bs = int(rng.choice([16, 32, 64]))
     B = int(rng.integers(1, 10))
     q_lens = [int(x) for x in rng.choice([1, 1, 2, 4, 4, 5, 8, 9, 16, 17, 24, 33], size=B)]
     ctxs = [int(max(q, rng.choice([q, q + 1, 31, 32, 33, 200, 1000, 2500]) + rng.integers(0, 40))) for q in q_lens]
-    fp8 = bool(seed % 3 == 2)
     q, kc, vc, bt, qsl = _attn_case(B, Hq, Hkv, D, q_lens, ctxs, bs, seed=seed)
     ks = vs = 1.0
     kw = {}
