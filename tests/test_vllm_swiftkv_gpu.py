@@ -151,7 +151,7 @@ def _sp_worker(rank, world, port, out_q):
             m.compute_logits = (lambda o: lambda hidden, sm=None: seen.append(o(hidden, sm)) or seen[-1])(orig)
         rng = np.random.default_rng(5)
         sched = H.MiniScheduler(16, 400)
-        for i, n in enumerate((37, 64, 5, 90)):
+        for i, n in enumerate((37, 64, 5, 91, 20)):      # 217 prompt tokens, 5 per decode step: odd, padded to a multiple of SP
             sched.add(f"r{i}", [int(t) for t in rng.integers(0, V, size=n)])
         toks, logits = [], []
         for _ in range(5):
@@ -171,7 +171,7 @@ def _sp_worker(rank, world, port, out_q):
 
 
 def test_swiftkv_model_sp2_shift_matches_single_process():
-    """SwiftKV under Ulysses SP = 2 with shift parallelism: the first half runs Ulysses for the 196-token prefill step and
+    """SwiftKV under Ulysses SP = 2 with shift parallelism: the first half runs Ulysses for the 217-token prefill step (padded) and
     the shift replica for decode steps, the C7 all-gather hands every token to the second half, which always runs in TP = 2
     (one kv head per rank): logits equal the single-process run's."""
     import socket
@@ -195,8 +195,21 @@ def test_swiftkv_model_sp2_shift_matches_single_process():
 
     (_, _, ref_toks, ref_logits, _), = launch(1)
     for _, rank, toks, logits, shared in launch(2):
-        for a, b in zip(ref_logits, logits):
+        # a request is compared for as long as both runs fed it the same tokens: two parallel layouts of a bf16 model may
+        # break a near-tie differently, after which the sequences (and logits) legitimately differ
+        same = {rid: True for rid in ref_toks[0]}
+        compared = 0
+        for step, (a, b) in enumerate(zip(ref_logits, logits)):
             assert a.shape == b.shape
-            scale = float(np.abs(a).max())
-            assert np.allclose(a, b, atol=0.05 * scale, rtol=0), (rank, float(np.abs(a - b).max()), scale)
+            for row, rid in enumerate(ref_toks[step]):          # rows follow the runner's request order = insertion order
+                if not same[rid]:
+                    continue
+                scale = float(np.abs(a[row]).max())
+                assert np.allclose(a[row], b[row], atol=0.05 * scale, rtol=0), (rank, step, rid, float(np.abs(a[row] - b[row]).max()))
+                compared += 1
+                if ref_toks[step][rid] != toks[step][rid]:
+                    top = np.sort(a[row])[-2:]
+                    assert top[1] - top[0] < 0.05 * scale, (rank, step, rid, "tokens differ without a near-tie")
+                    same[rid] = False
+        assert compared >= 15 and sum(same.values()) >= 3, (compared, same)
         assert shared is True, "the Ulysses model and the shift replica must run ONE decode half (model_runner.py:767-773)"
