@@ -95,6 +95,7 @@ _SIGNATURES = {
     "aic_ulysses_reorder_split_kv": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_int32), c_void_p]),
     "aic_debug_attn_trace": (c_int, [c_void_p, c_int]),
     "aic_debug_attn_layout": (c_int, [c_int, c_int]),
+    "aic_debug_attn_light": (c_int, [c_int]),
     "aic_row_gather": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64),
                                POINTER(c_int32), c_void_p, c_int, c_int, c_void_p]),
     "aic_rejection_workspace_bytes": (c_size_t, [c_int, c_int]),
@@ -140,6 +141,10 @@ def lib() -> ctypes.CDLL:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `make -C {CSRC}` "
                               "(or __graft_entry__.build()); there is no fallback implementation")
+        # torch first: PyTorch-ROCm ships its own libamdhip64, and the library must bind to the HIP runtime torch
+        # initialises (loaded the other way round the process holds two runtimes and this one sees no device: found when
+        # a script touched lib() before importing torch)
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)

@@ -79,6 +79,10 @@ struct AttnParams {
   int direct;
   int mark_final;
   int64_t* trace;  // debug (aic_debug_attn_trace): per workgroup {start, end (100 MHz ticks), HW_ID | XCC_ID << 32, kind}
+  // token-range splits >= light_from take light_pct % of a full split's tiles (100: all equal): the short workgroups that
+  // will share their CU with a long-draft workgroup (pick_light_splits)
+  int light_from;
+  int light_pct;
 };
 
 // 16-byte load of KV bytes, non-temporal: every byte of the cache is read once per call, and with the default
@@ -334,9 +338,20 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
   const int n_parts = P.n_splits * R;
   const int part = by * R + range;
   const int tiles_total = (ctx + kTile - 1) / kTile;
-  const int tiles_per_part = (tiles_total + n_parts - 1) / n_parts;
-  const int t_begin = part * tiles_per_part * kTile;
-  const int t_end = min(ctx, t_begin + tiles_per_part * kTile);
+  int t_begin, t_end;
+  if (P.light_pct == 100) {
+    const int tiles_per_part = (tiles_total + n_parts - 1) / n_parts;
+    t_begin = part * tiles_per_part * kTile;
+    t_end = min(ctx, t_begin + tiles_per_part * kTile);
+  } else {
+    // parts of the splits >= light_from weigh light_pct, the others 100: cumulative weight -> tile boundaries
+    const int lf = P.light_from * R;
+    const int w_all = lf * 100 + (n_parts - lf) * P.light_pct;
+    const int c0 = min(part, lf) * 100 + max(0, part - lf) * P.light_pct;
+    const int c1 = min(part + 1, lf) * 100 + max(0, part + 1 - lf) * P.light_pct;
+    t_begin = (tiles_total * c0 / w_all) * kTile;
+    t_end = min(ctx, (tiles_total * c1 / w_all) * kTile);
+  }
 
   const int64_t kv_row = static_cast<int64_t>(Hkv) * HD;  // elements between consecutive tokens of a page
   const_i32_ptr btab = (const_i32_ptr)(P.block_table + static_cast<int64_t>(req) * P.max_blocks);
@@ -1238,6 +1253,7 @@ using namespace aic;
 
 static int64_t* g_attn_trace = nullptr;
 static int g_attn_trace_cap = 0;
+static int g_light_pct = 0;   // aic_debug_attn_light: weight of the light splits in percent (0 = the default, 100 = off)
 static int g_force_hpw = 0, g_force_splits = 0;   // aic_debug_attn_layout (tools/microbench.py sweeps); 0 = choose
 
 // Layout of the short body for a call whose query lengths the host knows: kv heads per workgroup (4, 2 or 1: the four
@@ -1275,6 +1291,13 @@ int aic_debug_attn_trace(int64_t* buf, int capacity_wgs) {
 
 // debug: force the short body's heads per workgroup (4 / 2 / 1) and / or split count for host-partitioned calls
 // (0 = let pick_short_layout choose); every setting computes the same result
+// debug: weight (percent of a full split's tiles) of the short-body splits that share CUs with long-draft workgroups in the
+// one-grid launch; 0 = the built-in value, 100 = equal splits
+int aic_debug_attn_light(int pct) {
+  g_light_pct = pct;
+  return AIC_OK;
+}
+
 int aic_debug_attn_layout(int heads_per_wg, int splits) {
   g_force_hpw = heads_per_wg;
   g_force_splits = splits;
@@ -1389,6 +1412,8 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   P.out_stride = out_stride;
   P.direct = 0;
   P.mark_final = 0;
+  P.light_from = n_splits;
+  P.light_pct = 100;
 
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
@@ -1455,6 +1480,24 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
       const int long_x = n_long * num_kv_heads;
       const int n_long_wg = long_x * n_splits_long * long_z, n_long_pad = (n_long_wg + 7) / 8 * 8;
       const int short_x = (P.n_items + 7) / 8 * 8;
+      // The dispatcher places the long workgroups (first in the grid) one per CU, then the short ones on the EMPTY CUs
+      // first: only the last min(n_long_wg, short_wg) short workgroups — whole trailing token-range splits, the grid being
+      // split-major — share a CU with a long one, and those run 7-10 % longer (per-workgroup trace, tools/microbench.py
+      // trace with AIC_TRACE_DETAIL: 31 short + 1 long, last 64 of 256: 86.7 against 80.3 us; 30 + 2, last 128: 89.6
+      // against 81.5; 62 + 2 at 64 requests: 167.5 against 156.6).  Those splits get a shorter token range.
+      // Only when the boundary falls (nearly) between two splits: a split that is partly shared would keep full ranges on
+      // workgroups that are slowed as well and become the tail (59 + 5 requests, 160 long workgroups against splits of 120:
+      // 192 -> 196 us).  Measured with equal / 92 % / 88 % ranges: a 32-request lane with one 33-token draft 97.5 / 94.6 /
+      // 93.5 us, with two drafts 102.5 / 100.0 / 99.5 us.
+      if (n_splits > 1 && short_wg <= cu_count()) {
+        const int first_shared = short_wg - std::min(n_long_wg, short_wg);
+        const int rem = first_shared % short_x;
+        const int from = (first_shared + short_x / 2) / short_x;            // first split whose workgroups are shared
+        if ((rem * 8 <= short_x || rem * 8 >= 7 * short_x) && from > 0 && from < n_splits) {
+          P.light_from = from;
+          P.light_pct = g_light_pct ? g_light_pct : 90;
+        }
+      }
       profile_begin(s);
       const dim3 pgrid(static_cast<unsigned>(n_long_pad + short_wg));
       P.trace = (g_attn_trace && static_cast<int>(pgrid.x) <= g_attn_trace_cap) ? g_attn_trace : nullptr;

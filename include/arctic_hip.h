@@ -161,6 +161,7 @@ int aic_debug_attn_trace(int64_t* buf, int capacity_wgs);
 /* debug aid: force the short attention body's kv heads per workgroup (4 / 2 / 1) and / or its cross-workgroup split count
  * for host-partitioned calls (0 = chosen by the library); every setting computes the same result. */
 int aic_debug_attn_layout(int heads_per_wg, int splits);
+int aic_debug_attn_light(int pct);
 
 /* ------------------------------------------------------------------------------------------
  * (f)-1  SwiftKV token selection — the index_fn gathers of LlamaSwiftKVModel.swiftkv_select

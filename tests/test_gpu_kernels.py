@@ -507,6 +507,47 @@ def test_verify_attention_full_size_properties(kv):
         assert torch.allclose(a[rows].cpu(), want, atol=1e-3, rtol=2 ** -8), (i, (a[rows].cpu() - want).abs().max())
 
 
+def test_verify_attention_lighter_trailing_splits():
+    """One-grid launch of a lane-sized batch (30 requests of up to 32 rows + 2 long drafts, ~4100-token contexts): the short
+    workgroups that will share a CU with a long-draft workgroup are the last in the grid — whole trailing token-range
+    splits — and get a shorter range (AttnParams::light_from / light_pct).  Any weight must give the same attention:
+    against equal splits, against the generic path, and against the oracle on a sample of requests."""
+    from arcticinference_amd import _native as N
+    torch.manual_seed(7)
+    B, Hq, Hkv, D, bs = 32, 32, 8, 128, 16
+    rng = np.random.RandomState(11)
+    q_lens = [1] * 22 + [4] * 6 + [8, 5] + [33, 20]
+    rng.shuffle(q_lens)
+    ctxs = [int(x) for x in rng.randint(3700, 4353, size=B)]
+    max_blocks = max((c + bs - 1) // bs for c in ctxs)
+    nb = B * max_blocks
+    bt = torch.randperm(nb)[:B * max_blocks].view(B, max_blocks).to(torch.int32)
+    kc = torch.randn(nb, bs, Hkv, D, device=DEV, dtype=torch.bfloat16)
+    vc = torch.randn(nb, bs, Hkv, D, device=DEV, dtype=torch.bfloat16)
+    q = torch.randn(sum(q_lens), Hq, D, device=DEV, dtype=torch.bfloat16)
+    qsl = torch.tensor(np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32), device=DEV)
+    seq = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
+    run = lambda **kw: _ops().verify_attention(q, kc, vc, bt.to(DEV), seq, qsl, max(q_lens), max(ctxs), D ** -0.5, **kw).float()
+    try:
+        outs = {}
+        for pct in (100, 0, 75, 50):                 # equal splits, the built-in weight, two exaggerated ones
+            N.lib().aic_debug_attn_light(pct)
+            outs[pct] = run(q_lens_host=q_lens)
+    finally:
+        N.lib().aic_debug_attn_light(0)
+    generic = run()
+    for pct, o in outs.items():
+        assert torch.allclose(o, outs[100], atol=1e-3, rtol=2 ** -8), (pct, (o - outs[100]).abs().max())
+        assert torch.allclose(o, generic, atol=1e-3, rtol=2 ** -8), (pct, (o - generic).abs().max())
+    assert not torch.equal(outs[50], outs[100])          # the weights did move the split boundaries
+    qs = qsl.cpu().numpy()
+    for i in (0, int(np.argmax(q_lens)), B - 1):
+        rows = slice(int(qs[i]), int(qs[i + 1]))
+        want = O.verify_attention(q[rows].cpu(), kc.cpu(), vc.cpu(), bt[i:i + 1], [ctxs[i]],
+                                  np.array([0, q_lens[i]], dtype=np.int32), D ** -0.5, 1.0, 1.0)
+        assert torch.allclose(outs[0][rows].cpu(), want, atol=1e-3, rtol=2 ** -8), (i, (outs[0][rows].cpu() - want).abs().max())
+
+
 # ------------------------------------------------------------------------------------------------
 # A7-A10 LSTM speculator
 # ------------------------------------------------------------------------------------------------

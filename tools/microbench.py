@@ -162,6 +162,17 @@ def attn_trace(n_short=59, n_long=5, q_short=1, q_long=33, ctx=4224, Hq=32, Hkv=
     per_cu = {}
     for c, k in zip(cu, t[:, 3]):
         per_cu.setdefault(int(c), []).append(int(k))
+    if os.environ.get("AIC_TRACE_DETAIL"):     # which short workgroups (by launch index) share a CU with a long one, and how long they ran
+        long_cus = set(cu[t[:, 3] == 1].tolist())
+        idx = np.nonzero(t[:, 3] == 0)[0]
+        shared = np.array([int(cu[i]) in long_cus for i in idx])
+        dur = (end - start)[idx]
+        n = len(idx)
+        print(f"  short workgroups in launch order, 16 bins: share of each bin on a CU with a long workgroup / median duration")
+        for b in range(16):
+            sl = slice(b * n // 16, (b + 1) * n // 16)
+            print(f"    bin {b:2d}: shared {shared[sl].mean():.2f}  dur {np.median(dur[sl]):6.1f}  (max {dur[sl].max():6.1f})")
+        print(f"  shared: median dur {np.median(dur[shared]) if shared.any() else 0:.1f}; alone: {np.median(dur[~shared]) if (~shared).any() else 0:.1f}")
     mix = sorted((tuple(sorted(v)) for v in per_cu.values()))
     from collections import Counter
     print(f"  CUs used {len(per_cu)}; CUs with both kinds {len(both)}; per-CU mix {Counter(mix).most_common(6)}")
@@ -253,6 +264,18 @@ if __name__ == "__main__":
         attn_mix(59, 5, q_long=33, Hq=4, Hkv=1)
         attn_mix(64, 0, q_short=8)         # every request at two row tiles
         attn_mix(64, 0, q_short=4)
+    if "light" in what:    # weight of the short-body splits that share CUs with long-draft workgroups (percent; 100 = equal)
+        for pct in (100, 96, 92, 88, 84):
+            N.lib().aic_debug_attn_light(pct)
+            print("light", pct)
+            attn_ql([1] * 31 + [33], jitter=256)
+            attn_ql([1] * 30 + [20, 33], jitter=256)
+            attn_ql([1] * 29 + [10, 20, 33], jitter=256)
+            attn_ql([1] * 63 + [33], jitter=256)
+            attn_ql([1] * 62 + [20] * 2, jitter=256)
+            attn_ql([1] * 59 + [33] * 5, jitter=256)
+            attn_ql([1] * 59 + [12] * 3 + [33] * 2, Hq=4, Hkv=1, jitter=256)
+        N.lib().aic_debug_attn_light(0)
     if "ql" in what:
         for jit in (0, 256):
             attn_ql([1] * 64, jitter=jit)
@@ -267,6 +290,8 @@ if __name__ == "__main__":
         attn_trace(56, 8)
         attn_trace(62, 2)
         attn_trace(63, 1)
+        attn_trace(30, 2)
+        attn_trace(31, 1)
     if "mix" in what:
         attn_mix(64, 0)
         attn_mix(59, 5)
