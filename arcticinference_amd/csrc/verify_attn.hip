@@ -79,9 +79,10 @@ struct AttnParams {
   int direct;
   int mark_final;
   int64_t* trace;  // debug (aic_debug_attn_trace): per workgroup {start, end (100 MHz ticks), HW_ID | XCC_ID << 32, kind}
-  // token-range splits >= light_from take light_pct % of a full split's tiles (100: all equal): the short workgroups that
-  // will share their CU with a long-draft workgroup (pick_light_splits)
-  int light_from;
+  // short workgroups whose index in the launch (by * light_stride + bx) is >= light_first take light_pct % of a full
+  // split's tiles (100: all equal): the ones that will share their CU with a long-draft workgroup
+  int light_first;
+  int light_stride;
   int light_pct;
 };
 
@@ -344,11 +345,18 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
     t_begin = part * tiles_per_part * kTile;
     t_end = min(ctx, t_begin + tiles_per_part * kTile);
   } else {
-    // parts of the splits >= light_from weigh light_pct, the others 100: cumulative weight -> tile boundaries
-    const int lf = P.light_from * R;
-    const int w_all = lf * 100 + (n_parts - lf) * P.light_pct;
-    const int c0 = min(part, lf) * 100 + max(0, part - lf) * P.light_pct;
-    const int c1 = min(part + 1, lf) * 100 + max(0, part + 1 - lf) * P.light_pct;
+    // every split of THIS item weighs light_pct if its workgroup is one of the sharing ones, else 100: cumulative
+    // weights -> tile boundaries (all workgroups of an item compute the same boundaries)
+    int c0 = 0, c1 = 0, w_all = 0;
+    for (int b2 = 0; b2 < P.n_splits; ++b2) {
+      const int w = (b2 * P.light_stride + bx >= P.light_first) ? P.light_pct : 100;
+      if (b2 < by) c0 += w * R;
+      if (b2 == by) {
+        c0 += w * range;
+        c1 = c0 + w;
+      }
+      w_all += w * R;
+    }
     t_begin = (tiles_total * c0 / w_all) * kTile;
     t_end = min(ctx, (tiles_total * c1 / w_all) * kTile);
   }
@@ -1412,7 +1420,8 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   P.out_stride = out_stride;
   P.direct = 0;
   P.mark_final = 0;
-  P.light_from = n_splits;
+  P.light_first = 0;
+  P.light_stride = 0;
   P.light_pct = 100;
 
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1481,21 +1490,18 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
       const int n_long_wg = long_x * n_splits_long * long_z, n_long_pad = (n_long_wg + 7) / 8 * 8;
       const int short_x = (P.n_items + 7) / 8 * 8;
       // The dispatcher places the long workgroups (first in the grid) one per CU, then the short ones on the EMPTY CUs
-      // first: only the last min(n_long_wg, short_wg) short workgroups — whole trailing token-range splits, the grid being
-      // split-major — share a CU with a long one, and those run 7-10 % longer (per-workgroup trace, tools/microbench.py
-      // trace with AIC_TRACE_DETAIL: 31 short + 1 long, last 64 of 256: 86.7 against 80.3 us; 30 + 2, last 128: 89.6
-      // against 81.5; 62 + 2 at 64 requests: 167.5 against 156.6).  Those splits get a shorter token range.
-      // Only when the boundary falls (nearly) between two splits: a split that is partly shared would keep full ranges on
-      // workgroups that are slowed as well and become the tail (59 + 5 requests, 160 long workgroups against splits of 120:
-      // 192 -> 196 us).  Measured with equal / 92 % / 88 % ranges: a 32-request lane with one 33-token draft 97.5 / 94.6 /
-      // 93.5 us, with two drafts 102.5 / 100.0 / 99.5 us.
+      // first: only the last (long + short - CUs) short workgroups share a CU with a long one, and those run 7-10 % longer
+      // (per-workgroup trace, tools/microbench.py trace with AIC_TRACE_DETAIL: 31 short + 1 long, last 64 of 256: 86.7
+      // against 80.3 us; 30 + 2, last 128: 89.6 against 81.5; 62 + 2 at 64 requests, last 64: 167.5 against 156.6).  Those
+      // workgroups get a shorter token range; the other splits of their items take up the difference.  Measured with equal
+      // / 92 % / 88 % ranges: a 32-request lane with one 33-token draft 97.8 / 95.5 / 94.1 us, with two 101.3 / 99.5 / 98.6;
+      // 63 requests + one draft 182.8 / 176.5 / 174.4 us, 62 + 2: 182.9 / 178.1 / 177.1, 59 + 5: 185.9 / 184.8 / 183.9.
       if (n_splits > 1 && short_wg <= cu_count()) {
-        const int first_shared = short_wg - std::min(n_long_wg, short_wg);
-        const int rem = first_shared % short_x;
-        const int from = (first_shared + short_x / 2) / short_x;            // first split whose workgroups are shared
-        if ((rem * 8 <= short_x || rem * 8 >= 7 * short_x) && from > 0 && from < n_splits) {
-          P.light_from = from;
-          P.light_pct = g_light_pct ? g_light_pct : 90;
+        const int first_shared = std::max(0, cu_count() - n_long_wg);
+        if (first_shared > 0 && first_shared < short_wg) {
+          P.light_first = first_shared;
+          P.light_stride = short_x;
+          P.light_pct = g_light_pct ? g_light_pct : 88;
         }
       }
       profile_begin(s);
