@@ -414,7 +414,11 @@ class HotPathEngine:
         # Steps follow each other closely in what they do, so: if the previous step used the draft model, enqueue it
         # now (it runs while the host updates the trees) and drop it should suffix decoding win; if the previous step
         # was taken by suffix decoding, wait for the suffix result and run the draft model only if nobody was taken.
-        early_lstm = use_lstm and (spec.draft_model_per_request or self.suffix_cache is None or not L.suffix_won_last)
+        # With interleaved lanes the wait costs nothing (the GPU is busy with the other lane), while a dropped launch is
+        # 0.45 ms of GPU time — and after a step without a suffix winner the next one usually has one: never early there.
+        interleaved = len(self.__dict__.get("_lanes", ())) > 1
+        early_lstm = use_lstm and (spec.draft_model_per_request or self.suffix_cache is None or
+                                   (not L.suffix_won_last and not interleaved))
         if early_lstm:
             lstm_out = self.drafter.generate_proposals(rej.last_token, self.hidden, spec.num_speculative_tokens,
                                                        hidden_index=rej.hidden_index)
