@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes
 import os
 import subprocess
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libarctic_hip.so"
@@ -96,6 +96,9 @@ _SIGNATURES = {
     "aic_debug_attn_trace": (c_int, [c_void_p, c_int]),
     "aic_debug_attn_layout": (c_int, [c_int, c_int]),
     "aic_debug_attn_light": (c_int, [c_int]),
+    "aic_debug_attn_graph": (c_int, [c_int]),
+    "aic_debug_attn_long_splits": (c_int, [c_int]),
+    "aic_debug_attn_graph_stats": (c_int, [POINTER(c_uint64), POINTER(c_uint64)]),
     "aic_row_gather": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64),
                                POINTER(c_int32), c_void_p, c_int, c_int, c_void_p]),
     "aic_rejection_workspace_bytes": (c_size_t, [c_int, c_int]),
@@ -178,3 +181,10 @@ def torch_dtype_code(dtype) -> int:
     if dtype not in table:
         raise NativeError(AIC_ERR_UNSUPPORTED, f"unsupported dtype {dtype}")
     return table[dtype]
+
+
+def attn_graph_stats():
+    """(graph launches of aic_verify_attention_layers so far, distinct graphs instantiated)."""
+    a, b = c_uint64(), c_uint64()
+    check(lib().aic_debug_attn_graph_stats(ctypes.byref(a), ctypes.byref(b)))
+    return a.value, b.value

@@ -27,7 +27,12 @@
 #include <type_traits>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstring>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include <cstdlib>
 
 #include "aic_common.h"
@@ -1255,12 +1260,52 @@ static int pick_splits(int n_items, int max_seq_len, int min_tiles_per_split, in
   return best;
 }
 
+
+// ---- launch recording (aic_verify_attention_layers) ---------------------------------------------------------------
+// Every launch of the call path below goes through launch(): normally hipLaunchKernelGGL; while a Recorder is installed
+// (thread-local) the launch is written down instead — kernel, geometry, argument bytes — so that a whole run of layers can
+// be replayed as one HIP graph whose kernel nodes only have their parameters refreshed per step.
+struct LaunchRec {
+  void* func;
+  dim3 grid, block;
+  std::vector<char> blob;         // argument values, 16-byte aligned each
+  std::vector<uint32_t> offs;     // their offsets in blob
+};
+struct Recorder {
+  bool ok = true;                 // false: the call took a path that cannot be a plain kernel chain (side stream)
+  std::vector<LaunchRec> recs;
+};
+static thread_local Recorder* t_rec = nullptr;
+
+template <typename... Params, typename... Args>
+static void launch(void (*kernel)(Params...), dim3 grid, dim3 block, hipStream_t s, Args&&... args) {
+  static_assert(sizeof...(Params) == sizeof...(Args), "argument count");
+  if (t_rec == nullptr) {
+    hipLaunchKernelGGL(kernel, grid, block, 0, s, static_cast<Params>(args)...);
+    return;
+  }
+  LaunchRec r;
+  r.func = reinterpret_cast<void*>(kernel);
+  r.grid = grid;
+  r.block = block;
+  auto put = [&r](const auto& v) {
+    const size_t off = (r.blob.size() + 15) & ~static_cast<size_t>(15);
+    r.blob.resize(off + sizeof(v));
+    std::memcpy(r.blob.data() + off, &v, sizeof(v));
+    r.offs.push_back(static_cast<uint32_t>(off));
+  };
+  (put(static_cast<Params>(args)), ...);
+  t_rec->recs.push_back(std::move(r));
+}
+static int launch_ok(const char* what) { return t_rec ? AIC_OK : launch_status(what); }
+
 }  // namespace aic
 
 using namespace aic;
 
 static int64_t* g_attn_trace = nullptr;
 static int g_attn_trace_cap = 0;
+static int g_long_splits = 0; // aic_debug_attn_long_splits: split count of the long-draft part of a mixed call (0 = the default)
 static int g_light_pct = 0;   // aic_debug_attn_light: weight of the light splits in percent (0 = the default, 100 = off)
 static int g_force_hpw = 0, g_force_splits = 0;   // aic_debug_attn_layout (tools/microbench.py sweeps); 0 = choose
 
@@ -1379,13 +1424,24 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   }
   const int hgroups_s = num_kv_heads / hpw;              // head groups of the short launch
   const bool direct = split_lists && n_short > 0 && n_splits == 1;
-  int n_splits_long = (split_lists && n_long > 0) ? pick_splits(n_long * num_kv_heads, max_seq_len, 8, 2) : 0;
-  // the long part of a mixed call: its workgroups start first and should be gone well before the short ones end, without
-  // flooding the CUs' second slots with many short-lived workgroups.  Measured (tools/microbench.py, 4224-token contexts; long splits 2 / 4 / 8 / 16): a 32-request call (4 short splits) with one
-  // 33-token draft 163 / 114 / 97.5 / 106 us, a 64-request call (2 short splits) with five 212 / 191.7 / 197.1 / 197.2 us, with two
-  // 20-token drafts 198 / 180.7 / 183.2 / 195.9 us: twice the short part's split count — a long workgroup with half a short one's
-  // tokens — and never more than 8.
-  if (mixed) n_splits_long = std::min(n_splits_long, std::min(8, 2 * n_splits));
+  int n_splits_long = (split_lists && n_long > 0) ? pick_splits(n_long * num_kv_heads, max_seq_len, mixed ? 4 : 8, 2) : 0;
+  // The long part of a mixed call: its workgroups start first and should end with the short ones.  Per-workgroup traces
+  // (tools/microbench.py sptrace / longsplits, 4224-token contexts, profiles/r02_long_splits.txt): a short workgroup takes
+  // 4.3 + 0.30 X us with X = kv heads x requests of the call (X = 512 on one GPU, 64 on a rank of SP = 8), a long one
+  // (8.1 + 0.15 X) + 0.049 us per token of its range — a latency chain (request list -> lengths -> block table -> first
+  // tile, then one memory round trip per 32-token tile) that stretches with the load the short workgroups put on memory.
+  // Equal ends: tokens per long workgroup = 2.6 X - 70 (fitted a little generously), never under 4 tiles; X scales with
+  // the context length and halves with an fp8 cache.  r02's earlier rule (twice the short splits, at most 8) was fitted at
+  // X >= 256 only; a rank of SP = 8 (X = 64) gained 50.5 -> 36 us per layer with 63 + 1 requests, SP = 4 63.7 -> 56 us.
+  if (mixed) {
+    int cap = g_long_splits;
+    if (cap == 0) {
+      const double X = static_cast<double>(num_kv_heads) * batch * (kv8 ? 0.5 : 1.0) * max_seq_len / 4224.0;
+      const double tokens = std::max(128.0 + 16.0 * (n_long - 1), 2.6 * X - 70.0);
+      cap = std::max(2, std::min(32, static_cast<int>(std::ceil(max_seq_len / tokens))));
+    }
+    n_splits_long = std::min(n_splits_long, cap);
+  }
   auto fits = [&](int parts) { return static_cast<size_t>(parts) * rows * (head_size + 2) * sizeof(float) <= workspace_bytes; };
   while (n_splits > 1 && !fits(n_splits)) --n_splits;
   while (n_splits_long > 1 && !fits(n_splits_long)) --n_splits_long;
@@ -1430,11 +1486,11 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   auto launch_short = [&](int mtq_, int hpw_, dim3 grid_) {
 #define AIC_SHORT(MTQ_, HPW_)                                                                  \
   if (d64)                                                                                     \
-    hipLaunchKernelGGL((verify_attn_kernel<MTQ_, HPW_, false, 4, 64>), grid_, dim3(256), 0, s, P); \
+    launch(verify_attn_kernel<MTQ_, HPW_, false, 4, 64>, grid_, dim3(256), s, P);                  \
   else if (kv8)                                                                                \
-    hipLaunchKernelGGL((verify_attn_kernel<MTQ_, HPW_, true>), grid_, dim3(256), 0, s, P);     \
+    launch(verify_attn_kernel<MTQ_, HPW_, true>, grid_, dim3(256), s, P);                      \
   else                                                                                         \
-    hipLaunchKernelGGL((verify_attn_kernel<MTQ_, HPW_, false>), grid_, dim3(256), 0, s, P);
+    launch(verify_attn_kernel<MTQ_, HPW_, false>, grid_, dim3(256), s, P);
     if (mtq_ == 0) {
       if (hpw_ == 4) { AIC_SHORT(0, 4) } else if (hpw_ == 2) { AIC_SHORT(0, 2) } else { AIC_SHORT(0, 1) }
     } else if (mtq_ == 1) {
@@ -1445,7 +1501,7 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
 #undef AIC_SHORT
   };
   if (!split_lists) {
-    profile_begin(s);
+    if (!t_rec) profile_begin(s);
     // query lengths unknown on the host: rows per request in the common case decide the tile shape; long
     // drafts of a mixed batch take extra row groups (re-reading their KV through L2)
     const int avg_rows = (num_tokens + batch - 1) / batch * G;
@@ -1454,7 +1510,7 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
     P.n_items = batch * hgroups;
     dim3 grid(static_cast<unsigned>((P.n_items + 7) / 8 * 8 * P.m_groups), n_splits, 1);
     launch_short(mtq, hpw, grid);
-    profile_end(s);
+    if (!t_rec) profile_end(s);
   } else {
     // the caller partitioned the batch: `short_reqs` have q_len * G <= 32 rows (one pass of the short body, one or
     // two MFMA row tiles chosen per workgroup: verify_attn_body_dual), `long_reqs` go through the shared-tile body
@@ -1504,12 +1560,11 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
           P.light_pct = g_light_pct ? g_light_pct : 88;
         }
       }
-      profile_begin(s);
+      if (!t_rec) profile_begin(s);
       const dim3 pgrid(static_cast<unsigned>(n_long_pad + short_wg));
       P.trace = (g_attn_trace && static_cast<int>(pgrid.x) <= g_attn_trace_cap) ? g_attn_trace : nullptr;
 #define AIC_PAIR_LAUNCH(HPW_, KV8_)                                                                             \
-  hipLaunchKernelGGL((verify_attn_pair_kernel<HPW_, KV8_, 0>), pgrid, dim3(256), 0, s, P, PL, n_long_wg, n_long_pad, long_x, \
-                     n_splits_long, short_x);
+  launch(verify_attn_pair_kernel<HPW_, KV8_, 0>, pgrid, dim3(256), s, P, PL, n_long_wg, n_long_pad, long_x, n_splits_long, short_x);
       if (hpw == 4) {
         if (kv8) { AIC_PAIR_LAUNCH(4, true) } else { AIC_PAIR_LAUNCH(4, false) }
       } else if (hpw == 2) {
@@ -1518,12 +1573,16 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
         if (kv8) { AIC_PAIR_LAUNCH(1, true) } else { AIC_PAIR_LAUNCH(1, false) }
       }
 #undef AIC_PAIR_LAUNCH
-      profile_end(s);
+      if (!t_rec) profile_end(s);
       n_short = n_long = 0;  // both done
     }
     const bool overlap = n_short > 0 && n_long > 0;
     const bool short_first = false;
-    if (n_short > 0) profile_begin(s);  // bench.py's roofline figure: the short-request kernel alone (the begin
+    if (overlap && t_rec) {      // a fork / join over the side stream is not a plain kernel chain
+      t_rec->ok = false;
+      return AIC_OK;
+    }
+    if (n_short > 0 && !t_rec) profile_begin(s);  // bench.py's roofline figure: the short-request kernel alone (the begin
                                         // marker sits before the fork so that it delays neither kernel's start)
     if (overlap) {
       if ((rc = side_stream(&side)) != AIC_OK) return rc;
@@ -1537,11 +1596,11 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
       PL.n_splits = n_splits_long;
       dim3 grid(static_cast<unsigned>(n_long * num_kv_heads), n_splits_long, (max_rows + per_block_rows - 1) / per_block_rows);
       if (d64)
-        hipLaunchKernelGGL((verify_attn_long4_kernel<false, 64>), grid, dim3(256), 0, overlap ? side->stream : s, PL);
+        launch(verify_attn_long4_kernel<false, 64>, grid, dim3(256), overlap ? side->stream : s, PL);
       else if (kv8)
-        hipLaunchKernelGGL(verify_attn_long4_kernel<true>, grid, dim3(256), 0, overlap ? side->stream : s, PL);
+        launch(verify_attn_long4_kernel<true, 128>, grid, dim3(256), overlap ? side->stream : s, PL);
       else
-        hipLaunchKernelGGL(verify_attn_long4_kernel<false>, grid, dim3(256), 0, overlap ? side->stream : s, PL);
+        launch(verify_attn_long4_kernel<false, 128>, grid, dim3(256), overlap ? side->stream : s, PL);
       if (overlap) AIC_HIP_TRY(hipEventRecord(side->join, side->stream));
       return AIC_OK;
     };
@@ -1552,20 +1611,123 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
       P.n_items = n_short * hgroups_s;
       dim3 grid(static_cast<unsigned>((P.n_items + 7) / 8 * 8), n_splits, 1);
       launch_short(mtq_short, hpw, grid);
-      profile_end(s);
+      if (!t_rec) profile_end(s);
     }
     if (n_long > 0 && short_first && (rc = launch_long()) != AIC_OK) return rc;
     if (overlap) AIC_HIP_TRY(hipStreamWaitEvent(s, side->join, 0));
   }
-  if ((rc = launch_status("verify_attn_kernel")) != AIC_OK) return rc;
+  if ((rc = launch_ok("verify_attn_kernel")) != AIC_OK) return rc;
   if (P.direct && !P.mark_final) return AIC_OK;   // every row of the call is already final: no combine launch
   if (d64)
-    hipLaunchKernelGGL(verify_attn_combine_kernel<64>, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s, P.ws_o,
-                       P.ws_ml, n_parts_total, static_cast<int>(rows), num_q_heads, static_cast<uint16_t*>(out), out_stride);
+    launch(verify_attn_combine_kernel<64>, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), s, P.ws_o, P.ws_ml, n_parts_total,
+           static_cast<int>(rows), num_q_heads, static_cast<uint16_t*>(out), out_stride);
   else
-    hipLaunchKernelGGL(verify_attn_combine_kernel<128>, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s, P.ws_o,
-                       P.ws_ml, n_parts_total, static_cast<int>(rows), num_q_heads, static_cast<uint16_t*>(out), out_stride);
-  return launch_status("verify_attn_combine_kernel");
+    launch(verify_attn_combine_kernel<128>, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), s, P.ws_o, P.ws_ml, n_parts_total,
+           static_cast<int>(rows), num_q_heads, static_cast<uint16_t*>(out), out_stride);
+  return launch_ok("verify_attn_combine_kernel");
+}
+
+// ---- a run of layers as one graph launch ------------------------------------------------------------------------------
+// 32 layers are 64 kernel launches per engine step, ~4.4 us of host time each (profiles/r02_microbench.txt, graph probe):
+// more than the kernels themselves take once the sequence is sharded 8 ways.  The launches of one step form a plain chain
+// whose SHAPE (which kernel at which position) repeats from step to step while grids and arguments change, so the chain is
+// kept as an instantiated HIP graph per shape and each step only rewrites the kernel nodes' parameters
+// (hipGraphExecKernelNodeSetParams, ~0.7 us per node) and launches it once.
+struct LayerGraph {
+  int device;
+  std::vector<void*> funcs;           // the shape: kernel of every node, in order
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+  std::vector<hipGraphNode_t> nodes;
+  uint64_t last_use;
+};
+static std::mutex g_graph_mu;
+static std::vector<LayerGraph> g_graphs;
+static uint64_t g_graph_tick = 0;
+static std::atomic<int> g_graph_mode{1};          // aic_debug_attn_graph: 0 = always launch kernel by kernel
+static std::atomic<unsigned> g_layers_calls{0};
+static std::atomic<uint64_t> g_graph_launches{0}, g_graph_builds{0};
+constexpr size_t kMaxLayerGraphs = 24;
+
+static int replay_as_graph(const Recorder& rec, hipStream_t s) {
+  int device = 0;
+  AIC_HIP_TRY(hipGetDevice(&device));
+  const size_t n = rec.recs.size();
+  std::vector<std::vector<void*>> argv(n);
+  std::vector<hipKernelNodeParams> kp(n);
+  for (size_t i = 0; i < n; ++i) {
+    const LaunchRec& r = rec.recs[i];
+    argv[i].resize(r.offs.size());
+    for (size_t a = 0; a < r.offs.size(); ++a) argv[i][a] = const_cast<char*>(r.blob.data()) + r.offs[a];
+    kp[i] = hipKernelNodeParams{};
+    kp[i].func = r.func;
+    kp[i].gridDim = r.grid;
+    kp[i].blockDim = r.block;
+    kp[i].sharedMemBytes = 0;
+    kp[i].kernelParams = argv[i].data();
+    kp[i].extra = nullptr;
+  }
+  std::lock_guard<std::mutex> lock(g_graph_mu);
+  LayerGraph* g = nullptr;
+  for (LayerGraph& c : g_graphs) {
+    if (c.device != device || c.funcs.size() != n) continue;
+    bool same = true;
+    for (size_t i = 0; i < n && same; ++i) same = c.funcs[i] == rec.recs[i].func;
+    if (same) { g = &c; break; }
+  }
+  if (g == nullptr) {
+    if (g_graphs.size() >= kMaxLayerGraphs) {     // drop the shape that has not been seen for the longest time
+      size_t victim = 0;
+      for (size_t i = 1; i < g_graphs.size(); ++i)
+        if (g_graphs[i].last_use < g_graphs[victim].last_use) victim = i;
+      (void)hipGraphExecDestroy(g_graphs[victim].exec);
+      (void)hipGraphDestroy(g_graphs[victim].graph);
+      g_graphs.erase(g_graphs.begin() + static_cast<long>(victim));
+    }
+    LayerGraph c;
+    c.device = device;
+    c.nodes.resize(n);
+    AIC_HIP_TRY(hipGraphCreate(&c.graph, 0));
+    for (size_t i = 0; i < n; ++i) {
+      const hipError_t e = hipGraphAddKernelNode(&c.nodes[i], c.graph, i ? &c.nodes[i - 1] : nullptr, i ? 1 : 0, &kp[i]);
+      if (e != hipSuccess) {
+        (void)hipGraphDestroy(c.graph);
+        AIC_HIP_TRY(e);
+      }
+      c.funcs.push_back(rec.recs[i].func);
+    }
+    const hipError_t e = hipGraphInstantiate(&c.exec, c.graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+      (void)hipGraphDestroy(c.graph);
+      AIC_HIP_TRY(e);
+    }
+    g_graphs.push_back(std::move(c));
+    g = &g_graphs.back();
+    g_graph_builds.fetch_add(1, std::memory_order_relaxed);
+  } else {
+    for (size_t i = 0; i < n; ++i) AIC_HIP_TRY(hipGraphExecKernelNodeSetParams(g->exec, g->nodes[i], &kp[i]));
+  }
+  g->last_use = ++g_graph_tick;
+  AIC_HIP_TRY(hipGraphLaunch(g->exec, s));
+  g_graph_launches.fetch_add(1, std::memory_order_relaxed);
+  return AIC_OK;
+}
+
+// 0: kernel-by-kernel launches only; 1 (default): runs of >= 4 layers go out as one graph launch.
+int aic_debug_attn_long_splits(int splits) {
+  AIC_REQUIRE(splits >= 0 && splits <= 64, "bad split count");
+  g_long_splits = splits;
+  return AIC_OK;
+}
+int aic_debug_attn_graph(int on) {
+  g_graph_mode.store(on, std::memory_order_relaxed);
+  return AIC_OK;
+}
+// graph launches so far and distinct shapes instantiated
+int aic_debug_attn_graph_stats(uint64_t* launches, uint64_t* builds) {
+  if (launches) *launches = g_graph_launches.load(std::memory_order_relaxed);
+  if (builds) *builds = g_graph_builds.load(std::memory_order_relaxed);
+  return AIC_OK;
 }
 
 // The same call for a run of layers that share the step's geometry (one engine step of a stand-alone driver: q / out
@@ -1580,17 +1742,39 @@ int aic_verify_attention_layers(const void* q, int64_t q_stride, int64_t q_layer
                                 void* workspace, size_t workspace_bytes, int max_seq_len, const int32_t* short_reqs,
                                 int n_short, const int32_t* long_reqs, int n_long, void* stream) {
   AIC_REQUIRE(n_layers >= 0 && (n_layers == 0 || (k_caches && v_caches)), "bad layer tables");
-  for (int l = 0; l < n_layers; ++l) {
-    const uint16_t* ql = static_cast<const uint16_t*>(q) + static_cast<int64_t>(l) * q_layer_stride;
-    uint16_t* ol = static_cast<uint16_t*>(out) + static_cast<int64_t>(l) * out_layer_stride;
-    const int rc = aic_verify_attention_ex(ql, q_stride, k_caches[l], v_caches[l], block_stride, kv_dtype, k_scale, v_scale,
-                                           block_table, max_blocks_per_seq, seq_lens, query_start_loc, batch, num_tokens,
-                                           max_q_len, num_q_heads, num_kv_heads, head_size, block_size, sm_scale, ol,
-                                           out_stride, workspace, workspace_bytes, max_seq_len, short_reqs, n_short,
-                                           long_reqs, n_long, stream);
-    if (rc != AIC_OK) return rc;
+  auto layers = [&]() -> int {
+    for (int l = 0; l < n_layers; ++l) {
+      const uint16_t* ql = static_cast<const uint16_t*>(q) + static_cast<int64_t>(l) * q_layer_stride;
+      uint16_t* ol = static_cast<uint16_t*>(out) + static_cast<int64_t>(l) * out_layer_stride;
+      const int rc = aic_verify_attention_ex(ql, q_stride, k_caches[l], v_caches[l], block_stride, kv_dtype, k_scale, v_scale,
+                                             block_table, max_blocks_per_seq, seq_lens, query_start_loc, batch, num_tokens,
+                                             max_q_len, num_q_heads, num_kv_heads, head_size, block_size, sm_scale, ol,
+                                             out_stride, workspace, workspace_bytes, max_seq_len, short_reqs, n_short,
+                                             long_reqs, n_long, stream);
+      if (rc != AIC_OK || (t_rec && !t_rec->ok)) return rc;
+    }
+    return AIC_OK;
+  };
+  bool as_graph = n_layers >= 4 && g_graph_mode.load(std::memory_order_relaxed) != 0 && g_attn_trace == nullptr;
+  // with aic_profile_enable() on, every 8th call goes out kernel by kernel with its event pairs (graphs carry none): the
+  // live per-launch duration bench.py reports stays a sample of the same steps
+  const unsigned call = g_layers_calls.fetch_add(1, std::memory_order_relaxed);
+  if (as_graph && profile_enabled() && call % 8 == 0) as_graph = false;
+  if (as_graph) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
+      as_graph = false;                      // the caller is capturing its own graph: plain launches join that one
   }
-  return AIC_OK;
+  if (as_graph) {
+    Recorder rec;
+    t_rec = &rec;
+    const int rc = layers();
+    t_rec = nullptr;
+    if (rc != AIC_OK) return rc;
+    if (rec.ok && !rec.recs.empty()) return replay_as_graph(rec, static_cast<hipStream_t>(stream));
+    if (rec.ok) return AIC_OK;
+  }
+  return layers();
 }
 
 int aic_verify_attention(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,

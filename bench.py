@@ -52,6 +52,10 @@ def parse_args():
     ap.add_argument("--gen-len", type=int, default=256)
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-attn-graph", action="store_true",
+                    help="launch the attention layers kernel by kernel instead of as one HIP graph per step (A/B switch)")
+    ap.add_argument("--long-splits", type=int, default=0,
+                    help="A/B switch: force the split count of the long-draft part of mixed attention calls (0 = the library's rule)")
     ap.add_argument("--no-lstm", action="store_true")
     ap.add_argument("--kv-dtype", default="auto", choices=["auto", "fp8"], help="KV cache dtype (auto = bf16, the headline config)")
     ap.add_argument("--seed", type=int, default=0)
@@ -223,6 +227,10 @@ def main():
     from arcticinference_amd.speculator import ArcticLSTMSpeculator, LSTMSpeculatorConfig, random_lstm_weights
     from arcticinference_amd.workload import TokenSource
 
+    if args.no_attn_graph:
+        N.check(N.lib().aic_debug_attn_graph(0))
+    if args.long_splits:
+        N.check(N.lib().aic_debug_attn_long_splits(args.long_splits))
     shape = ModelShape(num_layers=args.layers)
     spec = SpecConfig(draft_model_per_request=args.draft_model_per_request)
     B, PL, GL = args.batch, args.prompt_len, args.gen_len
@@ -332,6 +340,7 @@ def main():
     gc.collect()
     gc.freeze()
     N.lib().aic_profile_enable(0 if os.environ.get("AIC_BENCH_NOPROFILE") else PROFILE_STRIDE)
+    graph0 = N.attn_graph_stats()
     gen_tokens[0] = 0
     replaced[0] = 0
     eng.stats = type(eng.stats)()
@@ -350,6 +359,7 @@ def main():
     tot_us, launches = ctypes.c_double(0), ctypes.c_int(0)
     N.lib().aic_profile_read(ctypes.byref(tot_us), ctypes.byref(launches))
     N.lib().aic_profile_enable(0)
+    graph1 = N.attn_graph_stats()
 
     red_dev = dev if args.dist_backend == "nccl" else "cpu"
     if dist is not None:
@@ -444,6 +454,8 @@ def main():
                              % (shape.num_layers, B, PL, GL, "bf16" if args.kv_dtype == "auto" else "fp8 e4m3")),
                 "global_batch": B, "prompt_len": PL, "gen_len": GL,
                 "lanes": n_lanes,
+                # attention layers of a step as one HIP graph launch: launches in the timed region, graphs instantiated in it
+                "attn_graph": {"launches": graph1[0] - graph0[0], "instantiated": graph1[1] - graph0[1]},
                 "schedule": ("one engine step over all %d requests per round" % B if n_lanes == 1 else
                              "%d lanes of %d requests, steps interleaved (one lane's host chain under the other's attention); "
                              "a round = every request advances one step" % (n_lanes, B // n_lanes)),

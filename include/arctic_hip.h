@@ -165,6 +165,15 @@ int aic_debug_attn_layout(int heads_per_wg, int splits);
  * long-draft workgroup of the one-grid launch (0 = the built-in 88, 100 = equal splits); every setting computes the same
  * result. */
 int aic_debug_attn_light(int pct);
+/* debug aid: upper bound on the cross-workgroup split count of the long-draft part of a mixed call (0 = chosen by the
+ * library); every setting computes the same result. */
+int aic_debug_attn_long_splits(int splits);
+/* aic_verify_attention_layers sends a run of >= 4 layers out as ONE HIP graph launch (an instantiated graph per sequence of
+ * kernels, its nodes' parameters rewritten per call) unless the stream is being captured by the caller.  0 switches that
+ * off (kernel-by-kernel launches), 1 (default) on; every setting computes the same result.  _stats: graph launches so far
+ * and distinct graphs instantiated. */
+int aic_debug_attn_graph(int on);
+int aic_debug_attn_graph_stats(uint64_t* launches, uint64_t* builds);
 
 /* ------------------------------------------------------------------------------------------
  * (f)-1  SwiftKV token selection — the index_fn gathers of LlamaSwiftKVModel.swiftkv_select

@@ -410,6 +410,58 @@ def test_verify_attention_plan_equals_direct_call():
         plan.layer_tables([dk[:-1]], [dv[:-1]])
 
 
+def test_verify_attention_layers_graph_equals_kernel_launches():
+    """aic_verify_attention_layers sends >= 4 layers out as one HIP graph whose kernel nodes are re-parameterised per call:
+    same bits as kernel-by-kernel launches, across calls that change the batch (same and different kernel sequences), and
+    the graph really is what ran (launch / instantiate counters)."""
+    import ctypes
+    from arcticinference_amd import _native as N
+    D, Hq, Hkv = 128, 32, 8
+    ops = _ops()
+    lib = N.lib()
+
+    def stats():
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        lib.aic_debug_attn_graph_stats(ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
+
+    cases = [([4, 33, 2, 17, 4], [900, 1300, 64, 2100, 33]),     # short + long drafts: the one-grid launch + combine
+             ([5, 40, 1, 9, 2], [700, 2300, 640, 100, 3300]),     # same kernels, other geometry: parameters only
+             ([4, 4, 2, 7, 4], [900, 1300, 64, 2100, 33]),        # short requests only: another kernel sequence
+             ([4, 33, 2, 17, 4], [900, 1300, 64, 2100, 33])]      # the first shape again: its graph is reused
+    try:
+        l0, b0 = stats()
+        for i, (q_lens, ctxs) in enumerate(cases):
+            q, kc, vc, bt, qsl = _attn_case(5, Hq, Hkv, D, q_lens, ctxs, 16, seed=11 + i)
+            dq, dbt = q.to(DEV), bt.to(DEV)
+            ks = [kc.to(DEV)] + [torch.randn_like(kc).to(DEV) for _ in range(4)]
+            vs = [vc.to(DEV)] + [torch.randn_like(vc).to(DEV) for _ in range(4)]
+            seq = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
+            dqsl = torch.tensor(qsl, device=DEV)
+            rs = ops.split_requests(q_lens, Hq // Hkv, DEV)
+            # q / out advance per layer here (layer stride = one q), so every layer's result is checked
+            qs = torch.stack([dq * (1.0 + 0.25 * l) for l in range(5)]).contiguous()
+            outs = {}
+            for mode in (0, 1):
+                lib.aic_debug_attn_graph(mode)
+                out = torch.full_like(qs, float("nan"))
+                plan = ops.VerifyAttentionPlan(qs[0], out[0], ks[0], dbt, seq, dqsl, max(q_lens), max(ctxs), D ** -0.5, req_split=rs)
+                a = plan._args
+                kt, vt, n, _keep = plan.layer_tables(ks, vs)
+                N.check(lib.aic_verify_attention_layers(a[0], a[1], qs.stride(0), kt, vt, n, *a[4:20], a[20], a[21],
+                                                        out.stride(0), *a[22:]))
+                torch.cuda.synchronize()
+                outs[mode] = out
+            assert torch.equal(outs[0], outs[1]), i
+            for l in (0, 4):
+                want = ops.verify_attention(qs[l], ks[l], vs[l], dbt, seq, dqsl, max(q_lens), max(ctxs), D ** -0.5, req_split=rs)
+                assert torch.equal(outs[1][l], want), (i, l)
+        l1, b1 = stats()
+        assert l1 - l0 == len(cases) and b1 - b0 == 2, (l0, b0, l1, b1)
+    finally:
+        lib.aic_debug_attn_graph(1)
+
+
 def test_verify_attention_unsupported_shapes():
     from arcticinference_amd._native import NativeError
     q, kc, vc, bt, qsl = _attn_case(1, 4, 1, 96, [2], [40], 16, seed=1)
@@ -546,6 +598,50 @@ def test_verify_attention_lighter_trailing_splits():
         want = O.verify_attention(q[rows].cpu(), kc.cpu(), vc.cpu(), bt[i:i + 1], [ctxs[i]],
                                   np.array([0, q_lens[i]], dtype=np.int32), D ** -0.5, 1.0, 1.0)
         assert torch.allclose(outs[0][rows].cpu(), want, atol=1e-3, rtol=2 ** -8), (i, (outs[0][rows].cpu() - want).abs().max())
+
+
+@pytest.mark.parametrize("Hkv", [8, 1])
+def test_verify_attention_long_draft_split_counts(Hkv):
+    """The long-draft part of a one-grid call takes 2-32 token-range splits by the load of the call (a rank of SP = 8 sees
+    one kv head: many short ranges).  Any count must give the same attention: forced counts 1, 3, 16, 32 (ranges down to
+    4 tiles, ragged last ranges) and the built-in choice, against the generic path and the oracle."""
+    from arcticinference_amd import _native as N
+    torch.manual_seed(5)
+    B, G, D, bs = 24, 4, 128, 16
+    Hq = Hkv * G
+    rng = np.random.RandomState(3)
+    q_lens = [1] * 15 + [4] * 5 + [33, 20, 12, 9]
+    rng.shuffle(q_lens)
+    ctxs = [int(x) for x in rng.randint(900, 4353, size=B)]
+    ctxs[int(np.argmax(q_lens))] = 4301
+    max_blocks = max((c + bs - 1) // bs for c in ctxs)
+    nb = B * max_blocks
+    bt = torch.randperm(nb).view(B, max_blocks).to(torch.int32)
+    kc = torch.randn(nb, bs, Hkv, D, device=DEV, dtype=torch.bfloat16)
+    vc = torch.randn(nb, bs, Hkv, D, device=DEV, dtype=torch.bfloat16)
+    q = torch.randn(sum(q_lens), Hq, D, device=DEV, dtype=torch.bfloat16)
+    qsl = torch.tensor(np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32), device=DEV)
+    seq = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
+    run = lambda **kw: _ops().verify_attention(q, kc, vc, bt.to(DEV), seq, qsl, max(q_lens), max(ctxs), D ** -0.5, **kw).float()
+    try:
+        outs = {}
+        for n in (0, 1, 3, 16, 32):
+            N.lib().aic_debug_attn_long_splits(n)
+            outs[n] = run(q_lens_host=q_lens)
+    finally:
+        N.lib().aic_debug_attn_long_splits(0)
+    generic = run()
+    for n, o in outs.items():
+        assert torch.allclose(o, generic, atol=1e-3, rtol=2 ** -8), (n, (o - generic).abs().max())
+    assert not torch.equal(outs[1], outs[32])            # the counts did change the reduction order
+    qs = qsl.cpu().numpy()
+    for i in np.argsort(q_lens)[-4:]:
+        rows = slice(int(qs[i]), int(qs[i + 1]))
+        want = O.verify_attention(q[rows].cpu(), kc.cpu(), vc.cpu(), bt[i:i + 1], [ctxs[i]],
+                                  np.array([0, q_lens[i]], dtype=np.int32), D ** -0.5, 1.0, 1.0)
+        for n in (0, 32):
+            got = outs[n][rows].cpu()
+            assert torch.allclose(got, want, atol=1e-3, rtol=2 ** -8), (i, n, (got - want).abs().max())
 
 
 # ------------------------------------------------------------------------------------------------

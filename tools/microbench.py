@@ -292,6 +292,15 @@ if __name__ == "__main__":
         attn_trace(63, 1)
         attn_trace(30, 2)
         attn_trace(31, 1)
+    if "sptrace" in what:        # the SP = 8 slice: which workgroups end the one-grid launch, by long split count
+        for sp in (24, 32):
+            N.lib().aic_debug_attn_long_splits(sp)
+            print("long splits", sp)
+            attn_trace(63, 1, Hq=4, Hkv=1)
+            attn_trace(31, 1, Hq=4, Hkv=1)
+        N.lib().aic_debug_attn_long_splits(0)
+        attn_mix(64, 0, Hq=4, Hkv=1)
+        attn_mix(32, 0, Hq=4, Hkv=1)
     if "mix" in what:
         attn_mix(64, 0)
         attn_mix(59, 5)
@@ -303,6 +312,16 @@ if __name__ == "__main__":
         attn_mix(59, 5, kv8=True)
         attn_mix(8, 1, Hq=4, Hkv=1)      # SP = 8 slice
         attn_mix(59, 5, Hq=4, Hkv=1)
+    if "longsplits" in what:
+        # long-draft split count of a mixed call on the slices a rank sees under SP (kv heads per rank 8 / 4 / 2 / 1)
+        L = N.lib()
+        for Hkv in (4, 2, 1):
+            for ns, nl in ((63, 1), (61, 3), (59, 5), (31, 1), (30, 2), (15, 1)):
+                for sp in (0, 12, 16, 20, 24, 32):
+                    L.aic_debug_attn_long_splits(sp)
+                    print("long splits %2d: " % sp, end="")
+                    attn_mix(ns, nl, Hq=4 * Hkv, Hkv=Hkv)
+        L.aic_debug_attn_long_splits(0)
     if "lstm" in what:
         lstm(64)
         lstm(32)
