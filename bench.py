@@ -64,9 +64,10 @@ def parse_args():
                     help="2: the live requests form two lanes of B/2 whose engine steps are interleaved — one lane's host "
                          "chain (tree update, suffix proposal, index build) runs while the GPU attends for the other; a "
                          "round still advances every request by one step.  1: every request in one engine step per round "
-                         "(host chain and GPU alternate).  0 (default): 2 on one GPU, 1 under SP, where the step is "
-                         "bound by the replicated host work and a second lane adds to it (measured r02, ms per round, 1 / 2 "
-                         "lanes: one GPU 7.00 / 6.68; rehearsed SP 2: 4.22 / 4.13, SP 4: 2.81 / 2.74, SP 8: 2.30 / 2.48)")
+                         "(host chain and GPU alternate).  0 (default): 2 on one GPU, 1 under SP, where a rank's launches are small "
+                         "and a second lane mostly adds their fixed costs (measured r02, ms per round, 1 / 2 "
+                         "lanes: one GPU 6.76 / 6.43; rehearsed SP 2: 4.02 / 3.86, SP 4: 2.72 / 2.64, SP 8: 2.10 / 2.19; the rehearsal has "
+                         "no collectives, a second lane doubles them on a real group)")
     ap.add_argument("--draft-model-per-request", action="store_true",
                     help="extension: requests that suffix decoding did not take still get the draft model's proposal in "
                          "steps where it took others (the reference gives the whole batch none, model_runner.py:616-618)")
@@ -229,6 +230,8 @@ def main():
 
     if args.no_attn_graph:
         N.check(N.lib().aic_debug_attn_graph(0))
+    elif os.environ.get("AIC_ATTN_GRAPH_MODE"):
+        N.check(N.lib().aic_debug_attn_graph(int(os.environ["AIC_ATTN_GRAPH_MODE"])))
     if args.long_splits:
         N.check(N.lib().aic_debug_attn_long_splits(args.long_splits))
     shape = ModelShape(num_layers=args.layers)
@@ -485,9 +488,11 @@ def main():
                          "launches": args.steps * shape.num_layers * n_lanes,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "every %d-th launch timed with a HIP event pair inside the library, on the launch's "
-                                 "stream; the kernel is verify_attn_pair_kernel (short-request and long-draft "
+                                 "stream%s; the kernel is verify_attn_pair_kernel (short-request and long-draft "
                                  "workgroups in one grid) or verify_attn_kernel when a step has no long draft"
-                                 % PROFILE_STRIDE},
+                                 % (PROFILE_STRIDE, "" if args.no_attn_graph else
+                                    ", in every 5th engine step (those go out kernel by kernel; the other steps' layers are "
+                                    "HIP graph launches, which carry no events)")},
         }
         if not args.no_cpu_baseline and world == 1:
             toks_per_req_step = st.emitted / max(args.steps * B, 1)

@@ -168,10 +168,12 @@ int aic_debug_attn_light(int pct);
 /* debug aid: upper bound on the cross-workgroup split count of the long-draft part of a mixed call (0 = chosen by the
  * library); every setting computes the same result. */
 int aic_debug_attn_long_splits(int splits);
-/* aic_verify_attention_layers sends a run of >= 4 layers out as ONE HIP graph launch (an instantiated graph per sequence of
- * kernels, its nodes' parameters rewritten per call) unless the stream is being captured by the caller.  0 switches that
- * off (kernel-by-kernel launches), 1 (default) on; every setting computes the same result.  _stats: graph launches so far
- * and distinct graphs instantiated. */
+/* aic_verify_attention_layers sends a run of >= 4 layers out as HIP graph launches (an instantiated graph per sequence of
+ * kernels, its nodes' parameters rewritten per call; 12 layers or more: the first 4 as one graph, the rest as a second)
+ * unless the stream is being captured by the caller.  0 switches that off (kernel-by-kernel launches), 1 (default) on,
+ * 2 = always a single graph; every setting computes the same result.  While aic_profile_enable() is on, every 5th call is
+ * launched kernel by kernel so that its launches can carry event pairs.  _stats: graph launches so far and distinct
+ * graphs instantiated. */
 int aic_debug_attn_graph(int on);
 int aic_debug_attn_graph_stats(uint64_t* launches, uint64_t* builds);
 

@@ -17,6 +17,7 @@ cut -c1-300 $O/bench_1lane.json
 timeout -k 10 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>> $O/bench.err | grep '^{' > $O/bench_20steps.json
 timeout -k 10 600 python bench.py --kv-dtype fp8 --no-cpu-baseline 2>> $O/bench.err | grep '^{' > $O/bench_fp8kv.json
 timeout -k 10 600 python tools/microbench.py attn fp8 mix mid ql lstm rej > $O/microbench.txt 2>&1
+bash tools/ab_sp.sh > $O/rehearsal_sp.txt 2>&1 || true
 echo microbench done
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $O/stats -o p -- python3 $R/bench.py --no-cpu-baseline > $O/stats.log 2>&1

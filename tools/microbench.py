@@ -322,6 +322,14 @@ if __name__ == "__main__":
                     print("long splits %2d: " % sp, end="")
                     attn_mix(ns, nl, Hq=4 * Hkv, Hkv=Hkv)
         L.aic_debug_attn_long_splits(0)
+    if "splight" in what:       # lighter trailing splits on SP slices, where the long workgroups are many and short
+        for Hkv in (1, 2, 4):
+            for ns, nl in ((63, 1), (61, 3), (59, 5), (31, 1), (29, 3)):
+                for pct in (100, 94, 0):
+                    N.lib().aic_debug_attn_light(pct)
+                    print("light %3d: " % pct, end="")
+                    attn_mix(ns, nl, Hq=4 * Hkv, Hkv=Hkv)
+        N.lib().aic_debug_attn_light(0)
     if "lstm" in what:
         lstm(64)
         lstm(32)
