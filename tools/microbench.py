@@ -330,6 +330,15 @@ if __name__ == "__main__":
                     print("light %3d: " % pct, end="")
                     attn_mix(ns, nl, Hq=4 * Hkv, Hkv=Hkv)
         N.lib().aic_debug_attn_light(0)
+    if "spsplits" in what:      # short-part split count on SP slices (aic_debug_attn_layout: heads per workgroup, splits)
+        for Hkv, hpws in ((1, (1,)), (2, (2, 1)), (4, (4, 2))):
+            for ns, nl in ((64, 0), (63, 1), (32, 0), (31, 1)):
+                for hpw in hpws:
+                    for sp in (0, 2, 3, 4, 6, 8, 12, 16):
+                        N.lib().aic_debug_attn_layout(hpw if sp else 0, sp)
+                        print("hpw %d splits %2d: " % (hpw, sp), end="")
+                        attn_mix(ns, nl, Hq=4 * Hkv, Hkv=Hkv)
+        N.lib().aic_debug_attn_layout(0, 0)
     if "lstm" in what:
         lstm(64)
         lstm(32)
