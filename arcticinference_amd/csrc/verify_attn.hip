@@ -1273,7 +1273,19 @@ struct LaunchRec {
 };
 struct Recorder {
   bool ok = true;                 // false: the call took a path that cannot be a plain kernel chain (side stream)
+  size_t n = 0;                   // records in use; the vector and its blobs keep their capacity from call to call
   std::vector<LaunchRec> recs;
+  void reset() {
+    ok = true;
+    n = 0;
+  }
+  LaunchRec& next() {
+    if (n == recs.size()) recs.emplace_back();
+    LaunchRec& r = recs[n++];
+    r.blob.clear();
+    r.offs.clear();
+    return r;
+  }
 };
 static thread_local Recorder* t_rec = nullptr;
 
@@ -1284,7 +1296,7 @@ static void launch(void (*kernel)(Params...), dim3 grid, dim3 block, hipStream_t
     hipLaunchKernelGGL(kernel, grid, block, 0, s, static_cast<Params>(args)...);
     return;
   }
-  LaunchRec r;
+  LaunchRec& r = t_rec->next();
   r.func = reinterpret_cast<void*>(kernel);
   r.grid = grid;
   r.block = block;
@@ -1295,7 +1307,6 @@ static void launch(void (*kernel)(Params...), dim3 grid, dim3 block, hipStream_t
     r.offs.push_back(static_cast<uint32_t>(off));
   };
   (put(static_cast<Params>(args)), ...);
-  t_rec->recs.push_back(std::move(r));
 }
 static int launch_ok(const char* what) { return t_rec ? AIC_OK : launch_status(what); }
 
@@ -1652,20 +1663,23 @@ constexpr size_t kMaxLayerGraphs = 24;
 static int replay_as_graph(const Recorder& rec, hipStream_t s) {
   int device = 0;
   AIC_HIP_TRY(hipGetDevice(&device));
-  const size_t n = rec.recs.size();
-  std::vector<std::vector<void*>> argv(n);
-  std::vector<hipKernelNodeParams> kp(n);
-  for (size_t i = 0; i < n; ++i) {
+  const size_t n = rec.n;
+  static thread_local std::vector<void*> argv;            // argument pointers of all nodes, node after node
+  static thread_local std::vector<hipKernelNodeParams> kp;
+  size_t n_args = 0;
+  for (size_t i = 0; i < n; ++i) n_args += rec.recs[i].offs.size();
+  argv.resize(n_args);
+  kp.resize(n);
+  for (size_t i = 0, at = 0; i < n; ++i) {
     const LaunchRec& r = rec.recs[i];
-    argv[i].resize(r.offs.size());
-    for (size_t a = 0; a < r.offs.size(); ++a) argv[i][a] = const_cast<char*>(r.blob.data()) + r.offs[a];
     kp[i] = hipKernelNodeParams{};
     kp[i].func = r.func;
     kp[i].gridDim = r.grid;
     kp[i].blockDim = r.block;
     kp[i].sharedMemBytes = 0;
-    kp[i].kernelParams = argv[i].data();
+    kp[i].kernelParams = argv.data() + at;
     kp[i].extra = nullptr;
+    for (size_t a = 0; a < r.offs.size(); ++a) argv[at++] = const_cast<char*>(r.blob.data()) + r.offs[a];
   }
   std::lock_guard<std::mutex> lock(g_graph_mu);
   LayerGraph* g = nullptr;
@@ -1772,13 +1786,14 @@ int aic_verify_attention_layers(const void* q, int64_t q_stride, int64_t q_layer
     const int head = (n_layers >= 12 && g_graph_mode.load(std::memory_order_relaxed) != 2) ? 4 : n_layers;
     for (int l0 = 0; l0 < n_layers;) {
       const int l1 = l0 == 0 ? head : n_layers;
-      Recorder rec;
+      static thread_local Recorder rec;
+      rec.reset();
       t_rec = &rec;
       const int rc = layers(l0, l1);
       t_rec = nullptr;
       if (rc != AIC_OK) return rc;
       if (!rec.ok) break;                    // a side-stream fork in this geometry: kernel by kernel from here
-      if (!rec.recs.empty()) {
+      if (rec.n > 0) {
         const int rc2 = replay_as_graph(rec, static_cast<hipStream_t>(stream));
         if (rc2 != AIC_OK) return rc2;
       }
