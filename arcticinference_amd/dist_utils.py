@@ -12,7 +12,16 @@ def _staged(group) -> bool:
     return dist.get_backend(group) == "gloo"
 
 
+def _need_dense(*tensors: torch.Tensor) -> None:
+    """RCCL takes dense buffers only; checked on every backend so that the gloo rehearsal cannot pass a view that the
+    real group would refuse."""
+    for t in tensors:
+        if not t.is_contiguous():
+            raise ValueError("collective buffers must be contiguous (got shape %s, strides %s)" % (tuple(t.shape), t.stride()))
+
+
 def all_gather_into_tensor(out: torch.Tensor, inp: torch.Tensor, group=None) -> None:
+    _need_dense(out, inp)
     if inp.is_cuda and _staged(group):
         n = dist.get_world_size(group)
         parts = [torch.empty(inp.shape, dtype=inp.dtype) for _ in range(n)]
@@ -23,6 +32,7 @@ def all_gather_into_tensor(out: torch.Tensor, inp: torch.Tensor, group=None) -> 
 
 
 def all_to_all_single(recv: torch.Tensor, send: torch.Tensor, group=None) -> None:
+    _need_dense(recv, send)
     if send.is_cuda and _staged(group):
         n = dist.get_world_size(group)
         src = send.cpu().contiguous()
@@ -42,6 +52,7 @@ def all_to_all_single(recv: torch.Tensor, send: torch.Tensor, group=None) -> Non
 
 def all_reduce(t: torch.Tensor, group=None) -> None:
     """Sum in place."""
+    _need_dense(t)
     if t.is_cuda and _staged(group):
         host = t.cpu()
         dist.all_reduce(host, group=group)
