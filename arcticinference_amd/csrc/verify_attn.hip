@@ -1788,9 +1788,14 @@ int aic_verify_attention_layers(const void* q, int64_t q_stride, int64_t q_layer
       const int l1 = l0 == 0 ? head : n_layers;
       static thread_local Recorder rec;
       rec.reset();
-      t_rec = &rec;
-      const int rc = layers(l0, l1);
-      t_rec = nullptr;
+      int rc;
+      {
+        struct Recording {                   // whatever ends the scope, later launches of this thread are real again
+          explicit Recording(Recorder* r) { t_rec = r; }
+          ~Recording() { t_rec = nullptr; }
+        } recording(&rec);
+        rc = layers(l0, l1);
+      }
       if (rc != AIC_OK) return rc;
       if (!rec.ok) break;                    // a side-stream fork in this geometry: kernel by kernel from here
       if (rec.n > 0) {

@@ -425,22 +425,23 @@ def test_verify_attention_layers_graph_equals_kernel_launches():
         lib.aic_debug_attn_graph_stats(ctypes.byref(a), ctypes.byref(b))
         return a.value, b.value
 
-    cases = [([4, 33, 2, 17, 4], [900, 1300, 64, 2100, 33]),     # short + long drafts: the one-grid launch + combine
-             ([5, 40, 1, 9, 2], [700, 2300, 640, 100, 3300]),     # same kernels, other geometry: parameters only
-             ([4, 4, 2, 7, 4], [900, 1300, 64, 2100, 33]),        # short requests only: another kernel sequence
-             ([4, 33, 2, 17, 4], [900, 1300, 64, 2100, 33])]      # the first shape again: its graph is reused
+    cases = [([4, 33, 2, 17, 4], [900, 1300, 64, 2100, 33], 5),     # short + long drafts: the one-grid launch + combine
+             ([5, 40, 1, 9, 2], [700, 2300, 640, 100, 3300], 5),     # same kernels, other geometry: parameters only
+             ([4, 4, 2, 7, 4], [900, 1300, 64, 2100, 33], 5),        # short requests only: another kernel sequence
+             ([4, 33, 2, 17, 4], [900, 1300, 64, 2100, 33], 5),      # the first shape again: its graph is reused
+             ([4, 33, 2, 17, 4], [900, 1300, 64, 2100, 33], 13)]     # 12 layers or more: a 4-layer graph, then the rest
     try:
         l0, b0 = stats()
-        for i, (q_lens, ctxs) in enumerate(cases):
+        for i, (q_lens, ctxs, L) in enumerate(cases):
             q, kc, vc, bt, qsl = _attn_case(5, Hq, Hkv, D, q_lens, ctxs, 16, seed=11 + i)
             dq, dbt = q.to(DEV), bt.to(DEV)
-            ks = [kc.to(DEV)] + [torch.randn_like(kc).to(DEV) for _ in range(4)]
-            vs = [vc.to(DEV)] + [torch.randn_like(vc).to(DEV) for _ in range(4)]
+            ks = [kc.to(DEV)] + [torch.randn_like(kc).to(DEV) for _ in range(L - 1)]
+            vs = [vc.to(DEV)] + [torch.randn_like(vc).to(DEV) for _ in range(L - 1)]
             seq = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
             dqsl = torch.tensor(qsl, device=DEV)
             rs = ops.split_requests(q_lens, Hq // Hkv, DEV)
             # q / out advance per layer here (layer stride = one q), so every layer's result is checked
-            qs = torch.stack([dq * (1.0 + 0.25 * l) for l in range(5)]).contiguous()
+            qs = torch.stack([dq * (1.0 + 0.25 * (l % 5)) for l in range(L)]).contiguous()
             outs = {}
             for mode in (0, 1):
                 lib.aic_debug_attn_graph(mode)
@@ -453,11 +454,12 @@ def test_verify_attention_layers_graph_equals_kernel_launches():
                 torch.cuda.synchronize()
                 outs[mode] = out
             assert torch.equal(outs[0], outs[1]), i
-            for l in (0, 4):
+            for l in (0, 3, 4, L - 1):
                 want = ops.verify_attention(qs[l], ks[l], vs[l], dbt, seq, dqsl, max(q_lens), max(ctxs), D ** -0.5, req_split=rs)
                 assert torch.equal(outs[1][l], want), (i, l)
         l1, b1 = stats()
-        assert l1 - l0 == len(cases) and b1 - b0 == 2, (l0, b0, l1, b1)
+        # one launch per 5-layer call, two for the 13-layer one; graphs: mixed x 5, short-only x 5, mixed x 4, mixed x 9
+        assert l1 - l0 == len(cases) + 1 and b1 - b0 == 4, (l0, b0, l1, b1)
     finally:
         lib.aic_debug_attn_graph(1)
 
