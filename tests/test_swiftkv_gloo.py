@@ -20,7 +20,17 @@ def _worker(rank, world, port, q):
         want_h = torch.cat([torch.arange(n * 4, dtype=torch.float32).view(n, 4)[:, :3] + 100 * r for r in range(world)])
         want_p = torch.cat([torch.arange(n) + 10 * r for r in range(world)])
         same = sp_all_gather([hid], 1, None)[0]
-        q.put((rank, bool(torch.equal(h, want_h) and torch.equal(p, want_p) and same is hid)))
+        # the seam itself refuses strided buffers on every backend (RCCL would; the staged gloo path must not hide it)
+        from arcticinference_amd import dist_utils
+        refused = 0
+        for call in (lambda: dist_utils.all_reduce(hid[:, :3]),
+                     lambda: dist_utils.all_gather_into_tensor(torch.empty(world * n, 3), hid[:, :3]),
+                     lambda: dist_utils.all_to_all_single(torch.empty(n, 4)[:, :2], hid[:, :2])):
+            try:
+                call()
+            except ValueError:
+                refused += 1
+        q.put((rank, bool(torch.equal(h, want_h) and torch.equal(p, want_p) and same is hid and refused == 3)))
     finally:
         dist.destroy_process_group()
 
