@@ -57,6 +57,9 @@ def parse_args():
     ap.add_argument("--long-splits", type=int, default=0,
                     help="A/B switch: force the split count of the long-draft part of mixed attention calls (0 = the library's rule)")
     ap.add_argument("--no-lstm", action="store_true")
+    ap.add_argument("--no-spec", action="store_true",
+                    help="comparison run, not the headline: speculation off (no suffix cache, no draft model) — every request "
+                         "decodes one token per step through the same attention + greedy sampling kernels")
     ap.add_argument("--kv-dtype", default="auto", choices=["auto", "fp8"], help="KV cache dtype (auto = bf16, the headline config)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--qlen-hist", action="store_true", help="diagnostic: histogram of per-request query lengths in the timed steps")
@@ -236,6 +239,9 @@ def main():
         N.check(N.lib().aic_debug_attn_long_splits(args.long_splits))
     shape = ModelShape(num_layers=args.layers)
     spec = SpecConfig(draft_model_per_request=args.draft_model_per_request)
+    if args.no_spec:
+        spec = SpecConfig(method="none", enable_suffix_decoding=False)
+        args.no_lstm = True
     B, PL, GL = args.batch, args.prompt_len, args.gen_len
     max_model_len = PL + GL + 64
     src = TokenSource(seed=args.seed)
@@ -450,11 +456,13 @@ def main():
             "dtype": "bf16",
             "data": "synthetic",
             "config": {
-                "workload": ("Llama-3.1-8B shapes (L=%d, Hq=32, Hkv=8, D=128, V=128256), arctic LSTM speculator k=3 "
-                             "(Ds=4096, fp8 head when padded batch <= 32) + suffix decoding, B=%d live requests, "
+                "workload": ("Llama-3.1-8B shapes (L=%d, Hq=32, Hkv=8, D=128, V=128256), %sB=%d live requests, "
                              "%d-token prompts, %d generated tokens each, greedy, KV cache %s; hot path only (verify "
                              "attention, acceptance, suffix + LSTM proposal, KV write); target dense layers synthetic"
-                             % (shape.num_layers, B, PL, GL, "bf16" if args.kv_dtype == "auto" else "fp8 e4m3")),
+                             % (shape.num_layers,
+                                "SPECULATION OFF (comparison run: one token per request-step), " if args.no_spec else
+                                "arctic LSTM speculator k=3 (Ds=4096, fp8 head when padded batch <= 32) + suffix decoding, ",
+                                B, PL, GL, "bf16" if args.kv_dtype == "auto" else "fp8 e4m3")),
                 "global_batch": B, "prompt_len": PL, "gen_len": GL,
                 "lanes": n_lanes,
                 # attention layers of a step as one HIP graph launch: launches in the timed region, graphs instantiated in it
