@@ -25,6 +25,7 @@ import torch
 from . import ops
 from .speculator import ArcticLSTMSpeculator
 from .suffix_cache import SuffixCache, SuffixSpecResult
+from .vllm_plugin.runner_logic import INDEXING_REFERENCE, proposal_indexing
 
 MAX_SPEC_LEN = 32  # vllm.v1.sample.rejection_sampler.MAX_SPEC_LEN (model_runner.py:42, :716)
 
@@ -45,6 +46,10 @@ class SpecConfig:
     # whole batch's draft-model proposal).  False reproduces that; True is this build's extension: the draft model
     # still serves the requests suffix decoding did not take.
     draft_model_per_request: bool = False
+    # Where a request's row ends for the proposers (vllm_plugin/runner_logic.py): "reference" = the literal arithmetic of
+    # model_runner.py:623-636 / :696-718 run after :469-486 has advanced the row (sampled ids counted twice),
+    # "single_advance" = the row as the step left it.  None = the library default (the reference's).
+    proposal_indexing: Optional[str] = None
 
 
 @dataclass
@@ -171,6 +176,7 @@ class HotPathEngine:
         self.max_num_seqs, self.max_model_len = max_num_seqs, max_model_len
         self.drafter = speculator
         self.ulysses = ulysses
+        self._indexing = proposal_indexing(spec)
         self.sp = 1 if ulysses is None else ulysses.sp_size
         self.suffix_cache = SuffixCache(spec.suffix_cache_max_depth) if (
             spec.enable_suffix_decoding or spec.method == "suffix") else None
@@ -469,6 +475,14 @@ class HotPathEngine:
             return emitted
         _mark('host_parse')
         suffix = None
+        # `end_idx` of the proposers (runner_logic.py): the row end as committed above, or — "reference" indexing — the
+        # emitted ids counted a second time and written again behind themselves (model_runner.py:696-709)
+        end_prop = ntok
+        if self._indexing == INDEXING_REFERENCE:
+            end_prop = ntok + n_emit
+            pos = np.repeat(ntok, n_emit) + within
+            keep = pos < self.max_model_len                  # :701-707: the write is cut at max_model_len
+            self.token_ids_cpu[np.repeat(live, n_emit)[keep], pos[keep]] = flat_emit[keep]
         if self.suffix_cache is not None:
             self.suffix_cache.update_responses(req_ids, flat_emit, n_emit)   # _update_suffix_cache (:657-678)
             _mark('host_suffix_update')
@@ -477,7 +491,7 @@ class HotPathEngine:
             if not hasattr(self, "_suffix_stream"):
                 self._suffix_stream = torch.cuda.Stream(device=dev)
             with torch.cuda.stream(self._suffix_stream):
-                suffix = self._propose_suffix(live, req_ids, ntok, n_emit)
+                suffix = self._propose_suffix(live, req_ids, end_prop, n_emit)
             _mark('suffix_speculate_roundtrip')
         # (f) merge (:555-566, :595-601).  The LSTM tokens start their copy to the host (the reference's `.cpu()`,
         # arctic_proposer.py:166) but nothing here waits for it: which requests take the LSTM draft, and how many
@@ -509,7 +523,7 @@ class HotPathEngine:
             ev.record()
         L.lstm_prev = lstm_out
         _mark('host_draft_copy')
-        room = np.maximum(self.max_model_len - ntok - 1, 0)
+        room = np.maximum(self.max_model_len - end_prop - 1, 0)
         if suffix_won:
             idx = np.flatnonzero(took)
             rows = live[idx]
@@ -522,7 +536,7 @@ class HotPathEngine:
             # propose_arctic_draft_token_ids, model_runner.py:629-641); the per-request extension clamps per request
             k_batch = spec.num_speculative_tokens
             if not spec.draft_model_per_request:
-                k_batch = max(min(k_batch, self.max_model_len - int(ntok.max()) - 1), 0)
+                k_batch = max(min(k_batch, self.max_model_len - int(end_prop.max()) - 1), 0)
             gets = n_emit > 0
             if took is not None:
                 gets &= ~took

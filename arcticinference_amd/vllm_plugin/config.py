@@ -50,6 +50,9 @@ class ArcticSpeculativeSettings:
     suffix_max_spec_factor: float = 1.0
     suffix_max_spec_offset: float = 0.0
     suffix_min_token_prob: float = 0.1
+    # this build's one extra key: where a row ends for the proposers (runner_logic.py: "reference" | "single_advance");
+    # None = the library default, which is the reference's arithmetic
+    proposal_indexing: Optional[str] = None
 
     def __post_init__(self):
         use_suffix = self.method == "suffix" or (self.method is None and self.enable_suffix_decoding)
@@ -100,6 +103,7 @@ def _config_classes():
         suffix_max_spec_factor: float = 1.0
         suffix_max_spec_offset: float = 0.0
         suffix_min_token_prob: float = 0.1
+        proposal_indexing: Optional[str] = None     # runner_logic.py; not a key of the reference
 
     _classes = (ArcticParallelConfig, ArcticSpeculativeConfig)
     return _classes

@@ -30,7 +30,8 @@ import numpy as np
 import torch
 
 from . import step_context
-from .runner_logic import MAX_SPEC_LEN, arctic_max_spec_tokens, merge_proposals, min_suffix_score, suffix_query
+from .runner_logic import (INDEXING_REFERENCE, MAX_SPEC_LEN, arctic_max_spec_tokens, merge_proposals, min_suffix_score,
+                           proposal_end_index, proposal_indexing, rewrite_sampled, suffix_query)
 
 ARCTIC_METHODS = ("arctic", "suffix", "mlp_speculator")
 
@@ -481,7 +482,9 @@ def build_model_runner_patch():
             # the draft length is one value for the batch (:629-641) and depends on how many tokens each request accepts;
             # with every draft accepted it is smallest: only if even then it is the configured k is it known now
             nb = len(self.input_batch.req_ids)
-            worst_ends = [int(self.input_batch.num_tokens_no_spec[i]) + int(num_draft_tokens[i]) + 1 for i in range(nb)]
+            mode = proposal_indexing(self.speculative_config)
+            worst_ends = [proposal_end_index(int(self.input_batch.num_tokens_no_spec[i]) + int(num_draft_tokens[i]) + 1,
+                                             int(num_draft_tokens[i]) + 1, mode) for i in range(nb)]
             k = self.speculative_config.num_speculative_tokens
             if arctic_max_spec_tokens(k, worst_ends, self.max_model_len) != k:
                 return                                   # a request is close to max_model_len: take the exact late path
@@ -514,6 +517,7 @@ def build_model_runner_patch():
         # ---- proposals (model_runner.py:526-655, :680-744) -------------------------------------------
         def propose_suffix_draft_token_ids(self, sampled_token_ids, spec_token_ids=None):
             cfg, ib = self.speculative_config, self.input_batch
+            mode = proposal_indexing(cfg)
             results = [SuffixSpecResult() for _ in sampled_token_ids]
             ids, pats, kws, where = [], [], [], []
             for i, sampled in enumerate(sampled_token_ids):
@@ -521,9 +525,12 @@ def build_model_runner_patch():
                 if not sampled:
                     continue
                 # execute_model has already appended this step's sampled ids to the row and advanced num_tokens_no_spec
-                # (:469-486).  The reference adds len(sampled) to it a second time here (:698-699, :709), so its pattern
-                # ends with the sampled ids repeated; this build takes the row as it is (deviations).
-                end = int(ib.num_tokens_no_spec[i])
+                # (:469-486).  "reference" indexing adds len(sampled) to it a second time and writes the ids again, as
+                # :698-709 do; "single_advance" takes the row as it is (runner_logic.py).
+                start = int(ib.num_tokens_no_spec[i])
+                end = proposal_end_index(start, len(sampled), mode)
+                if mode == INDEXING_REFERENCE:
+                    rewrite_sampled(ib.token_ids_cpu[i], start, sampled, self.max_model_len)
                 if end >= self.max_model_len:
                     continue
                 q = suffix_query(ib.token_ids_cpu[i], end, spec_ids, self.max_model_len, cfg.suffix_cache_max_depth,
@@ -544,6 +551,7 @@ def build_model_runner_patch():
 
         def propose_arctic_draft_token_ids(self, scheduler_output, sampled_token_ids, previous_hidden_states=None):
             ib = self.input_batch
+            mode = proposal_indexing(self.speculative_config)
             last_tokens: List[int] = []
             k = self.speculative_config.num_speculative_tokens
             for i, sampled in enumerate(sampled_token_ids):
@@ -554,11 +562,18 @@ def build_model_runner_patch():
                     req_id = ib.req_ids[i]
                     st = self.requests[req_id]
                     sampled = [st.get_token_id(st.num_computed_tokens + scheduler_output.num_scheduled_tokens[req_id])]
-                end = int(ib.num_tokens_no_spec[i])        # the row already holds this step's sampled ids (see above)
+                start = int(ib.num_tokens_no_spec[i])      # the row already holds this step's sampled ids (see above)
+                end = proposal_end_index(start, n, mode)
                 k = min(k, self.max_model_len - end - 1)
                 if k <= 0:
                     continue
-                last_tokens.append(int(sampled[-1]))
+                if mode == INDEXING_REFERENCE:
+                    # :635-636: the last sampled id over [start, end), and the conditioning token read back from the row
+                    # (for a request without a sampled id that is the row's last known token, not `sampled`)
+                    ib.token_ids_cpu[i, start:end] = sampled[-1]
+                    last_tokens.append(int(ib.token_ids_cpu[i, end - 1]))
+                else:
+                    last_tokens.append(int(sampled[-1]))
             if k <= 0:
                 return [[] for _ in sampled_token_ids]
             early = self._arctic_early
@@ -603,7 +618,9 @@ def build_model_runner_patch():
             elif sc.method in ("arctic", "mlp_speculator"):
                 assert isinstance(self.drafter, ArcticProposer)
                 early = self._arctic_early
-                ends = [int(self.input_batch.num_tokens_no_spec[i]) for i in range(len(remaining))]
+                mode = proposal_indexing(sc)
+                ends = [proposal_end_index(self.input_batch.num_tokens_no_spec[i], len(remaining[i]), mode)
+                        for i in range(len(remaining))]
                 usable = (early is not None and all(len(s) > 0 for s in remaining)
                           and arctic_max_spec_tokens(sc.num_speculative_tokens, ends, self.max_model_len) == early[0])
                 prev = None

@@ -3,9 +3,55 @@
 stand-alone engine and by the vLLM patch (model_runner.py in this package)."""
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence, Tuple
 
 MAX_SPEC_LEN = 32  # vllm.v1.sample.rejection_sampler.MAX_SPEC_LEN
+
+# ---------------------------------------------------------------------------------------------------
+# Where a request's row ends when the proposers look at it.
+#
+# The reference's execute_model appends the step's sampled ids to token_ids_cpu and ADVANCES num_tokens_no_spec
+# (model_runner.py:469-486); propose_suffix_draft_token_ids (:696-709) and propose_arctic_draft_token_ids (:623-636)
+# then take `start_idx = num_tokens_no_spec[i]` and `end_idx = start_idx + len(sampled_ids)` once more and write the
+# sampled ids again at [start_idx, end_idx).  Both readings are available:
+#   "reference"       the literal arithmetic: the suffix pattern ends with the sampled ids repeated, every
+#                     `max_model_len - end_idx - 1` clamp is len(sampled_ids) tighter, the row is re-written;
+#   "single_advance"  the row is taken as execute_model left it (end_idx = num_tokens_no_spec[i]): the algorithm of the
+#                     reference's own simulator (`(prompt + response)[-max_depth:]`, simulator.py:70-90) and of the golden
+#                     fixtures.
+# Chosen by the speculative config key `proposal_indexing` (ArcticSpeculativeConfig / engine.SpecConfig) or, above it,
+# the environment variable ARCTIC_INFERENCE_PROPOSAL_INDEXING.  The default reproduces the reference.
+# ---------------------------------------------------------------------------------------------------
+INDEXING_REFERENCE = "reference"
+INDEXING_SINGLE_ADVANCE = "single_advance"
+INDEXING_MODES = (INDEXING_REFERENCE, INDEXING_SINGLE_ADVANCE)
+DEFAULT_INDEXING = INDEXING_REFERENCE
+INDEXING_ENV = "ARCTIC_INFERENCE_PROPOSAL_INDEXING"
+
+
+def proposal_indexing(config=None) -> str:
+    """The mode in force for a speculative config (any object with an optional `proposal_indexing` attribute)."""
+    mode = os.environ.get(INDEXING_ENV) or getattr(config, "proposal_indexing", None) or DEFAULT_INDEXING
+    if mode not in INDEXING_MODES:
+        raise ValueError(f"proposal_indexing must be one of {INDEXING_MODES}, got {mode!r}")
+    return mode
+
+
+def proposal_end_index(num_tokens_no_spec: int, num_sampled: int, mode: str) -> int:
+    """`end_idx` of the proposers (model_runner.py:623-624, :698-699) for a row execute_model has already advanced."""
+    return int(num_tokens_no_spec) + (int(num_sampled) if mode == INDEXING_REFERENCE else 0)
+
+
+def rewrite_sampled(row, start_idx: int, sampled_ids: Sequence[int], max_model_len: int) -> None:
+    """The row write of propose_suffix_draft_token_ids in "reference" mode (model_runner.py:701-709): the sampled ids
+    once more at [start_idx, end_idx), cut at max_model_len when the request is at the limit."""
+    end_idx = start_idx + len(sampled_ids)
+    if end_idx >= max_model_len:
+        room = max_model_len - start_idx          # numpy slicing rules, as in the reference (a negative bound wraps)
+        row[start_idx:max_model_len] = list(sampled_ids)[:room]
+    else:
+        row[start_idx:end_idx] = sampled_ids
 
 
 def suffix_query(row: Sequence[int], end_idx: int, spec_ids: Sequence[int], max_model_len: int, max_depth: int,

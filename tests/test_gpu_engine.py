@@ -11,13 +11,13 @@ from oracle.suffix_oracle import OracleSuffixCache
 pytestmark = pytest.mark.gpu
 
 
-def _build(method, with_lstm, head_size=128, per_request=False):
+def _build(method, with_lstm, head_size=128, per_request=False, indexing="single_advance"):
     from arcticinference_amd.engine import HotPathEngine, ModelShape, SpecConfig
     from arcticinference_amd.speculator import ArcticLSTMSpeculator, LSTMSpeculatorConfig, random_lstm_weights
     shape = ModelShape(num_layers=2, num_q_heads=8, num_kv_heads=4, head_size=head_size, hidden_size=512, vocab_size=2000,
                        block_size=16)
     spec = SpecConfig(method=method, num_speculative_tokens=3, enable_suffix_decoding=True,
-                      draft_model_per_request=per_request)
+                      draft_model_per_request=per_request, proposal_indexing=indexing)
     drafter = None
     if with_lstm:
         cfg = LSTMSpeculatorConfig(vocab_size=2000, input_hidden_dim=512, inner_dim="512", emb_dim="512", proj_dim="512")
@@ -26,30 +26,40 @@ def _build(method, with_lstm, head_size=128, per_request=False):
     return HotPathEngine(shape, spec, 4, 400, drafter, device="cuda", seed=0), spec
 
 
+@pytest.mark.parametrize("indexing", ["single_advance", "reference"])
 @pytest.mark.parametrize("method,with_lstm,head_size,per_request", [
     ("suffix", False, 128, False), ("arctic", True, 128, False), ("arctic", True, 64, False), ("arctic", True, 128, True)])
-def test_engine_steps_match_oracle_policy(method, with_lstm, head_size, per_request):
-    """per_request=False is the reference's rule: a step in which suffix decoding takes ANY request gives no draft-model
-    proposal to the others (model_runner.py:616-618); True is this build's extension (SpecConfig.draft_model_per_request)."""
+def test_engine_steps_match_oracle_policy(method, with_lstm, head_size, per_request, indexing):
+    """Per step, the engine's drafts (ids, lengths, which proposer) equal the restated reference lines
+    (oracle/runner_policy_oracle.py over an oracle SuffixCache) under BOTH readings of the proposal indexing
+    (runner_logic.py).  per_request=False is the reference's rule: a step in which suffix decoding takes ANY request gives
+    no draft-model proposal to the others (model_runner.py:616-618); True is this build's extension."""
     from arcticinference_amd.workload import TokenSource
-    from arcticinference_amd.vllm_plugin.runner_logic import MAX_SPEC_LEN
-    eng, spec = _build(method, with_lstm, head_size, per_request)
+    from policy_shadow import LSTM, ShadowPolicy, check_drafts
+    eng, spec = _build(method, with_lstm, head_size, per_request, indexing)
+    assert eng._indexing == indexing
+    # a repetitive source (so that suffix drafts are long) with doubled tokens here and there: only a pattern that ends
+    # in a repeated token can match more than one token under the reference's indexing
     src = TokenSource(vocab_size=2000, seed=3, n_motifs=3, motif_min=8, motif_max=16, p_motif=0.9)
     B, PL = 4, 96
-    streams = {r: src.stream(PL + 200, r) for r in range(B)}
+    streams = {}
+    for r in range(B):
+        s = np.asarray(src.stream(PL + 260, r)).copy()
+        if indexing == "reference":
+            s[1::2] = s[0::2][:len(s[1::2])]        # every token doubled: the literal pattern "...a a" finds matches
+        streams[r] = s
     eng.add_requests(list(range(B)), list(range(B)), [streams[r][:PL] for r in range(B)],
                      [int(streams[r][PL]) for r in range(B)])
-    orc = OracleSuffixCache(spec.suffix_cache_max_depth)
+    shadow = ShadowPolicy(method, 3, 400, indexing)
     for r in range(B):
-        orc.cache_prompt(r, [int(x) for x in streams[r][:PL]])
-        orc.update_response(r, [int(streams[r][PL])])
+        shadow.admit(r, streams[r][:PL], [int(streams[r][PL])])
 
     def truth(req, n):
         s = streams[req.req_id]
         return s[len(req.tokens):len(req.tokens) + n]
 
-    min_score = 0 if method == "suffix" else spec.num_speculative_tokens
-    used_suffix = used_long = used_lstm = 0
+    used = {"suffix": 0, "lstm": 0, "none": 0}
+    used_long = 0
     for step in range(30):
         before = [len(r.tokens) for r in eng.requests]
         drafts_before = [list(r.drafts) for r in eng.requests]
@@ -66,49 +76,55 @@ def test_engine_steps_match_oracle_policy(method, with_lstm, head_size, per_requ
                 else:
                     break
             assert len(toks) == want_acc + 1
-            orc.update_response(r.req_id, toks)
-        # the reference updates the cache for the whole batch first (_update_suffix_cache), then proposes
-        wants = [orc.speculate(r.req_id, r.tokens[-64:].tolist(), max_spec_tokens=min(MAX_SPEC_LEN, 64, 400 - len(r.tokens) - 1))
-                 for r in eng.requests]
-        takes = [bool(w.score >= min_score and w.token_ids) for w in wants]
+        wants, results = shadow.step([r.req_id for r in eng.requests], list(emitted))
+        if per_request:
+            # the extension: requests suffix decoding did not take still get the draft model's k tokens, clamped per request
+            for i, r in enumerate(eng.requests):
+                if not wants[i]:
+                    end = shadow.nts[r.req_id] + (len(emitted[i]) if indexing == "reference" else 0)
+                    wants[i] = [LSTM] * max(min(3, 400 - end - 1), 0)
         for i, r in enumerate(eng.requests):
-            if takes[i]:
-                assert r.drafts == wants[i].token_ids, (step, i)
-                used_suffix += 1
-                used_long += len(wants[i].token_ids) > 3
-            elif with_lstm and (per_request or not any(takes)):
-                assert len(r.drafts) == 3          # LSTM drafts (values checked in test_gpu_kernels)
-                used_lstm += 1
-            else:
-                assert r.drafts == []
-    assert used_suffix > 10 and used_long > 0, (used_suffix, used_long)
-    assert used_lstm > 0 or not with_lstm
+            kind = check_drafts(r.drafts, wants[i], (step, i))
+            used[kind] += 1
+            used_long += kind == "suffix" and len(wants[i]) > 3
+            assert np.array_equal(r.tokens, shadow.rows[r.req_id][:shadow.nts[r.req_id]])
+    if indexing == "single_advance":
+        assert used["suffix"] > 10 and used_long > 0, (used, used_long)
+    else:
+        assert used["suffix"] > 0 or method == "arctic", used
+    assert used["lstm"] > 0 or not with_lstm
     st = eng.stats
     assert st.emitted == sum(len(r.tokens) - 97 for r in eng.requests)
     assert st.accepted <= st.drafted and st.num_drafts > 0
     assert eng.suffix_cache._global_tree().selfcheck() == 0
 
 
+@pytest.mark.parametrize("indexing", ["single_advance", "reference"])
 @pytest.mark.parametrize("method,with_lstm", [("suffix", False), ("arctic", True)])
-def test_engine_runs_to_the_model_length_limit(method, with_lstm):
+def test_engine_runs_to_the_model_length_limit(method, with_lstm, indexing):
     """The reference's tests/unit_tests/test_arctic_spec_max_len.py asks that generation up to max_model_len (and 1, 2, 3
     tokens short of it) works with both speculative methods.  Here: requests run into the limit, drafts are clamped so
     that no request ever holds more than max_model_len tokens, finished requests leave the batch (it shrinks), and every
     emitted token is the target's."""
     from arcticinference_amd.workload import TokenSource
-    eng, spec = _build(method, with_lstm)
+    from policy_shadow import ShadowPolicy, check_drafts
+    eng, spec = _build(method, with_lstm, indexing=indexing)
     limit = eng.max_model_len                      # 400
     src = TokenSource(vocab_size=2000, seed=8, n_motifs=3, motif_min=8, motif_max=16, p_motif=0.9)
     plens = [limit - 3, limit - 40, limit - 12, limit - 90]
     streams = {r: src.stream(limit + 40, r) for r in range(4)}
     eng.add_requests(list(range(4)), list(range(4)), [streams[r][:plens[r]] for r in range(4)],
                      [int(streams[r][plens[r]]) for r in range(4)])
+    shadow = ShadowPolicy(method, 3, limit, indexing)
+    for r in range(4):
+        shadow.admit(r, streams[r][:plens[r]], [int(streams[r][plens[r]])])
 
     def truth(req, n):
         s = streams[req.req_id]
         return s[len(req.tokens):len(req.tokens) + n]
 
     finished = 0
+    clamped = 0
     for step in range(400):
         for slot, r in enumerate(eng.requests):      # the scheduler retires a request at the length limit
             if r is not None and len(r.tokens) >= limit:
@@ -124,30 +140,35 @@ def test_engine_runs_to_the_model_length_limit(method, with_lstm):
             s = streams[r.req_id]
             assert toks == [int(x) for x in s[before[r.req_id]:before[r.req_id] + len(toks)]]
             assert len(r.tokens) + r.num_drafts <= limit, "a draft may not reach past the last position"
+        # drafts and their length clamps near the limit are the restated reference lines' (both indexing modes)
+        wants, _ = shadow.step([r.req_id for r in live], list(emitted))
+        for r, w in zip(live, wants):
+            kind = check_drafts(r.drafts, w, (step, r.req_id))
+            clamped += kind == "lstm" and len(w) < 3
     assert finished == 4
+    assert clamped > 0 or not with_lstm, "the draft model's length clamp (model_runner.py:629-641) never engaged"
 
 
+@pytest.mark.parametrize("indexing", ["single_advance", "reference"])
 @pytest.mark.parametrize("method,with_lstm", [("suffix", False), ("arctic", True)])
-def test_two_interleaved_lanes_follow_the_reference_policy_per_lane_step(method, with_lstm):
+def test_two_interleaved_lanes_follow_the_reference_policy_per_lane_step(method, with_lstm, indexing):
     """begin() / finish() with two lanes (bench.py --lanes 2): lane A's host half runs after lane B's device half has been
     enqueued.  Every lane step is an engine step over that lane's requests: emitted tokens are the target's, and the
-    drafts are what the oracle policy gives when it sees the same sequence of updates (lane by lane)."""
+    drafts are what the restated reference policy gives when it sees the same sequence of updates (lane by lane)."""
     from arcticinference_amd.workload import TokenSource
-    from arcticinference_amd.vllm_plugin.runner_logic import MAX_SPEC_LEN
-    eng, spec = _build(method, with_lstm)
+    from policy_shadow import ShadowPolicy, check_drafts
+    eng, spec = _build(method, with_lstm, indexing=indexing)
     src = TokenSource(vocab_size=2000, seed=5, n_motifs=3, motif_min=8, motif_max=16, p_motif=0.9)
     B, PL = 4, 96
     streams = {r: src.stream(PL + 200, r) for r in range(B)}
     eng.add_requests(list(range(B)), list(range(B)), [streams[r][:PL] for r in range(B)], [int(streams[r][PL]) for r in range(B)])
-    orc = OracleSuffixCache(spec.suffix_cache_max_depth)
+    shadow = ShadowPolicy(method, 3, 400, indexing)
     for r in range(B):
-        orc.cache_prompt(r, [int(x) for x in streams[r][:PL]])
-        orc.update_response(r, [int(streams[r][PL])])
+        shadow.admit(r, streams[r][:PL], [int(streams[r][PL])])
     truth = lambda req, n: streams[req.req_id][len(req.tokens):len(req.tokens) + n]
-    min_score = 0 if method == "suffix" else spec.num_speculative_tokens
     lanes = [[0, 2], [1, 3]]
     pending = [None, None]
-    used_suffix = used_lstm = 0
+    used = {"suffix": 0, "lstm": 0, "none": 0}
     for rnd in range(24):
         for l in (0, 1):
             c = pending[l]
@@ -156,22 +177,14 @@ def test_two_interleaved_lanes_follow_the_reference_policy_per_lane_step(method,
                 emitted = eng.finish(c)
                 for r, toks, b0 in zip(c.reqs, emitted, before):
                     assert toks == [int(x) for x in streams[r.req_id][b0:b0 + len(toks)]]
-                    orc.update_response(r.req_id, toks)
-                wants = [orc.speculate(r.req_id, r.tokens[-64:].tolist(), max_spec_tokens=min(MAX_SPEC_LEN, 64, 400 - len(r.tokens) - 1))
-                         for r in c.reqs]
-                takes = [bool(w.score >= min_score and w.token_ids) for w in wants]
-                for r, w, t in zip(c.reqs, wants, takes):
-                    if t:
-                        assert r.drafts == w.token_ids
-                        used_suffix += 1
-                    elif with_lstm and not any(takes):
-                        assert len(r.drafts) == 3
-                        used_lstm += 1
-                    else:
-                        assert r.drafts == []
+                wants, _ = shadow.step([r.req_id for r in c.reqs], list(emitted))
+                for r, w in zip(c.reqs, wants):
+                    used[check_drafts(r.drafts, w, (rnd, l, r.req_id))] += 1
             pending[l] = eng.begin(truth, lanes[l], lane=l)
             assert [eng.requests[i] for i in lanes[l]] == pending[l].reqs
-    assert used_suffix > 10 and (used_lstm > 0 or not with_lstm)
+    if indexing == "single_advance":
+        assert used["suffix"] > 10
+    assert used["lstm"] > 0 or not with_lstm
     for c in pending:
         eng.finish(c)
     assert eng.suffix_cache._global_tree().selfcheck() == 0

@@ -78,9 +78,10 @@ def _requests(n, plen, seed):
     return {f"r{i}": src.stream(plen + 260, i) for i in range(n)}
 
 
+@pytest.mark.parametrize("indexing", ["single_advance", "reference"])
 @pytest.mark.parametrize("method", ["suffix", "arctic"])
-def test_patched_execute_model_runs_the_hip_path_and_the_reference_policy(stub_vllm, method):
-    from oracle.suffix_oracle import OracleSuffixCache
+def test_patched_execute_model_runs_the_hip_path_and_the_reference_policy(stub_vllm, method, indexing):
+    from policy_shadow import LSTM, ShadowPolicy
     H.load_plugin()
     from vllm.attention.layer import Attention
     from vllm.config import SpeculativeConfig, set_current_vllm_config
@@ -88,8 +89,8 @@ def test_patched_execute_model_runs_the_hip_path_and_the_reference_policy(stub_v
     from vllm.v1.worker.gpu_model_runner import GPUModelRunner
     from arcticinference_amd.speculator import LSTMSpeculatorConfig, random_lstm_weights
     from arcticinference_amd.vllm_plugin import step_context
-    from arcticinference_amd.vllm_plugin.runner_logic import MAX_SPEC_LEN
     spec = SpeculativeConfig(method="suffix") if method == "suffix" else _lstm_spec_config()
+    spec.proposal_indexing = indexing
     cfg = _vllm_config(spec)
     H.init_single_process_groups(cfg)
     runner = GPUModelRunner(cfg, torch.device(DEV))
@@ -102,12 +103,16 @@ def test_patched_execute_model_runs_the_hip_path_and_the_reference_policy(stub_v
     runner.initialize_kv_cache((200, torch.bfloat16))
     B, PL, limit = 4, 96, 400
     streams = _requests(B, PL, seed=3)
+    if indexing == "reference":       # doubled tokens: only a pattern ending in a repeated token matches under this mode
+        for rid in streams:
+            s = np.asarray(streams[rid]).copy()
+            s[1::2] = s[0::2][:len(s[1::2])]
+            streams[rid] = s
     sched = H.MiniScheduler(16, limit)
     for rid, s in streams.items():
         sched.add(rid, [int(x) for x in s[:PL]])
     steer = Steered(runner, sched, streams)
-    orc = OracleSuffixCache(64)
-    min_score = 0 if method == "suffix" else 3
+    shadow = ShadowPolicy(method, 3, limit, indexing)
     step_context.calls.update(verify=0, fallback=0)
     Attention.calls = RejectionSampler.calls = 0
     used_suffix = used_lstm = long_drafts = 0
@@ -128,31 +133,33 @@ def test_patched_execute_model_runs_the_hip_path_and_the_reference_policy(stub_v
             seq = r["prompt"] + r["out"]
             toks = emitted[rid]
             assert toks == [int(x) for x in streams[rid][len(seq) - len(toks):len(seq)]], (step, rid)   # the target's tokens
-            if not orc.has_cached_prompt(rid):
-                orc.cache_prompt(rid, r["prompt"])
-            orc.update_response(rid, toks)
-        wants = {}
-        for rid in out.req_ids:
-            seq = sched.reqs[rid]["prompt"] + sched.reqs[rid]["out"]
-            wants[rid] = orc.speculate(rid, seq[-64:], max_spec_tokens=min(MAX_SPEC_LEN, 64, limit - len(seq) - 1))
-        takes = {rid: bool(w.score >= min_score) for rid, w in wants.items()}
+            if rid not in shadow.rows:
+                shadow.admit(rid, r["prompt"])
+        wants, _ = shadow.step(list(out.req_ids), [emitted[rid] for rid in out.req_ids])
         lstm_want = None
-        if method == "arctic" and not any(takes.values()):
+        if any(w and w[0] == LSTM for w in wants):
+            k = max(len(w) for w in wants)
             idx = torch.tensor([rows_of[rid] + len(emitted[rid]) - 1 for rid in out.req_ids], device=DEV)
             last = torch.tensor([emitted[rid][-1] for rid in out.req_ids], device=DEV)
-            lstm_want = runner.drafter.model.generate_proposals(last, hidden[idx], 3).cpu().tolist()
+            lstm_want = runner.drafter.model.generate_proposals(last, hidden[idx], k).cpu().tolist()
         for i, rid in enumerate(out.req_ids):
             got = out.spec_token_ids[i]
-            if takes[rid]:
-                assert got == wants[rid].token_ids, (step, rid)
-                used_suffix += bool(got)
-                long_drafts += len(got) > 3
-            elif lstm_want is not None:
+            if wants[i] and wants[i][0] == LSTM:
                 assert got == lstm_want[i], (step, rid)
                 used_lstm += 1
             else:
-                assert got == [], (step, rid)
-    assert used_suffix > 10 and long_drafts > 0
+                assert got == wants[i], (step, rid)
+                used_suffix += bool(got)
+                long_drafts += len(got) > 3
+            # the runner's row equals the shadow's after the step, incl. the reference mode's re-write behind the row's end
+            # (rejected drafts of the previous step may still sit further out in the runner's row)
+            j = runner.input_batch.req_id_to_index[rid]
+            upto = min(shadow.nts[rid] + (len(emitted[rid]) if indexing == "reference" else 0), limit)
+            assert np.array_equal(runner.input_batch.token_ids_cpu[j, :upto], shadow.rows[rid][:upto]), (step, rid)
+    if indexing == "single_advance":
+        assert used_suffix > 10 and long_drafts > 0
+    else:
+        assert used_suffix > 0 or method == "arctic"
     assert method == "suffix" or used_lstm > 0
     assert sched.stats["accepted"] > 0
     # routing: 28 steps x 2 layers; only the first (prefill, 96 tokens per request) went to vLLM's attention
