@@ -30,8 +30,8 @@ import numpy as np
 import torch
 
 from . import step_context
-from .runner_logic import (INDEXING_REFERENCE, MAX_SPEC_LEN, arctic_max_spec_tokens, merge_proposals, min_suffix_score,
-                           proposal_end_index, proposal_indexing, rewrite_sampled, suffix_query)
+from .runner_logic import (INDEXING_REFERENCE, MAX_SPEC_LEN, arctic_max_spec_tokens, hip_acceptance_kind, merge_proposals,
+                           min_suffix_score, proposal_end_index, proposal_indexing, rewrite_sampled, suffix_query)
 
 ARCTIC_METHODS = ("arctic", "suffix", "mlp_speculator")
 
@@ -67,6 +67,36 @@ def set_shift_parallel_mode(mode: Optional[bool]):
     finally:
         SP_TP_MODE = saved_mode
         parallel_state._TP = saved_tp
+
+
+# ---------------------------------------------------------------------------------------------------
+# random draws of the acceptance step, as vLLM's rejection sampler makes them (vllm==0.9.2, v1/sample/rejection_sampler.py,
+# recalled: generate_uniform_probs / sample_recovered_tokens; call site model_runner.py:405-411)
+# ---------------------------------------------------------------------------------------------------
+def draw_uniform_probs(num_tokens: int, num_draft_tokens, generators: dict, device) -> torch.Tensor:
+    """u ~ U[0,1), float64, one per draft position: ONE draw over all positions from the default generator, then the
+    positions of every request that owns a generator re-drawn with it; a request without draft tokens draws nothing."""
+    u = torch.rand((num_tokens,), dtype=torch.float64, device=device)
+    start = 0
+    for i, n in enumerate(num_draft_tokens):
+        if n == 0:
+            continue
+        g = generators.get(i)
+        if g is not None:
+            u[start:start + n].uniform_(generator=g)
+        start += n
+    return u
+
+
+def draw_recovery_noise(batch: int, vocab: int, num_draft_tokens, generators: dict, device) -> torch.Tensor:
+    """q ~ Exp(1), float32 [batch, vocab], ONE distribution per request: a whole-matrix draw from the default generator,
+    then the row of every seeded request that has draft tokens re-drawn with its generator."""
+    q = torch.empty((batch, vocab), dtype=torch.float32, device=device)
+    q.exponential_()
+    for i, g in generators.items():
+        if num_draft_tokens[i] > 0:
+            q[i].exponential_(generator=g)
+    return q
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -435,20 +465,23 @@ def build_model_runner_patch():
                         inputs_embeds=inputs_embeds)
 
         def _arctic_sample(self, logits, sampling_metadata, spec_decode_metadata, sample_hidden_states):
-            """Sampling + acceptance (model_runner.py:381-412).  All-greedy verify steps run ONE HIP launch that reads
-            the target rows and the bonus rows of `logits` in place; anything else keeps vLLM's sampler and
-            RejectionSampler (top-k / top-p / penalties live there)."""
+            """Sampling + acceptance (model_runner.py:381-412).  Verify steps whose sampling needs nothing beyond a
+            temperature run on the HIP acceptance kernels, reading the target rows of `logits` in place through
+            SpecDecodeMetadata.target_logits_indices (no gathered copy):
+              * all-greedy batches: ONE launch that also takes the bonus rows' arg-max (no separate sampler call);
+              * batches with random rows (temperature only; greedy rows may be mixed in): the bonus tokens come from
+                vLLM's sampler as in the reference (:394-399), then the uniforms and the Exp(1) recovery noise are drawn
+                exactly as vLLM's rejection sampler draws them — same calls, same order, per-request generators — and
+                aic_rejection_random accepts.
+            Anything else (top-k / top-p / min-p, penalties, bias, min_tokens, masks, logprobs: runner_logic.
+            hip_acceptance_kind) keeps vLLM's sampler + RejectionSampler."""
             if spec_decode_metadata is None:
                 return self.sampler(logits=logits, sampling_metadata=sampling_metadata)
             assert logits is not None
             md = spec_decode_metadata
             sm = sampling_metadata
-            plain_greedy = bool(getattr(sm, "all_greedy", False) and getattr(sm, "max_num_logprobs", None) is None
-                                and getattr(sm, "no_penalties", True) and getattr(sm, "allowed_token_ids_mask", None) is None
-                                and not getattr(sm, "bad_words_token_ids", None) and not getattr(sm, "logit_bias", None))
-            if plain_greedy:
-                plain_greedy = not any(getattr(sm, "logit_bias", None) or [])
-            if plain_greedy and logits.is_cuda:
+            kind = hip_acceptance_kind(sm) if logits.is_cuda else None
+            if kind == "greedy":
                 from vllm.v1.outputs import SamplerOutput
                 max_spec = max(int(max(md.num_draft_tokens)), 1)
                 rej = ops.rejection_sample(logits, md.draft_token_ids, md.cu_num_draft_tokens, None, max_spec,
@@ -460,6 +493,18 @@ def build_model_runner_patch():
             # indexing with a tensor copies: in-place edits of the sampler do not reach `logits`
             bonus_logits = logits[md.bonus_logits_indices]
             out = self.sampler(logits=bonus_logits, sampling_metadata=sampling_metadata)
+            if kind == "random":
+                n_draft = md.num_draft_tokens
+                max_spec = max(int(max(n_draft)), 1)
+                uniform = draw_uniform_probs(int(md.draft_token_ids.numel()), n_draft, sm.generators, logits.device)
+                noise = draw_recovery_noise(len(n_draft), logits.shape[-1], n_draft, sm.generators, logits.device)
+                rej = ops.rejection_sample(logits, md.draft_token_ids, md.cu_num_draft_tokens, out.sampled_token_ids, max_spec,
+                                           temperature=sm.temperature, uniform_probs=uniform, exp_noise=noise,
+                                           target_row_index=md.target_logits_indices.to(torch.int64))
+                self._arctic_rej = rej
+                self._arctic_maybe_draft_early(rej, sample_hidden_states, n_draft)
+                out.sampled_token_ids = rej.output_token_ids
+                return out
             target_logits = logits[md.target_logits_indices]
             out.sampled_token_ids = self.rejection_sampler(md, None, target_logits, out.sampled_token_ids, sampling_metadata)
             return out

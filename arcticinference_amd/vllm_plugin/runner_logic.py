@@ -93,3 +93,25 @@ def arctic_max_spec_tokens(num_speculative_tokens: int, end_indices: Sequence[in
         if m <= 0:
             break
     return m
+
+
+def hip_acceptance_kind(sm) -> Optional[str]:
+    """Which acceptance kernel serves a verify step with this vLLM SamplingMetadata: "greedy" (aic_rejection_greedy),
+    "random" (aic_rejection_random: temperature-only rows, greedy rows mixed in) or None (vLLM's sampler +
+    RejectionSampler: top-k / top-p / min-p, penalties, logit bias, min_tokens, bad words, allowed-token masks and
+    logprobs live there).  Read field by field the way vLLM 0.9.2's InputBatch fills it: `logit_bias` is a list with one
+    entry per request (None where unused) and is therefore never empty; `min_tokens` / `bad_words_token_ids` are dicts;
+    tensors are None when no request uses them."""
+    if getattr(sm, "max_num_logprobs", None) is not None or not getattr(sm, "no_penalties", True):
+        return None
+    if getattr(sm, "allowed_token_ids_mask", None) is not None or getattr(sm, "bad_words_token_ids", None):
+        return None
+    if any(b is not None and len(b) > 0 for b in (getattr(sm, "logit_bias", None) or ())):
+        return None
+    if getattr(sm, "min_tokens", None) or getattr(sm, "min_p", None) is not None:
+        return None
+    if getattr(sm, "all_greedy", False):
+        return "greedy"
+    if getattr(sm, "top_k", None) is not None or getattr(sm, "top_p", None) is not None:
+        return None
+    return "random" if getattr(sm, "temperature", None) is not None else None

@@ -28,6 +28,7 @@ class CachedRequestState:
     block_ids: List[int]
     num_computed_tokens: int = 0
     output_token_ids: List[int] = field(default_factory=list)
+    sampling_params: Any = None           # an object with .temperature (0 = greedy) and .seed, or None (greedy)
 
     @property
     def num_tokens(self) -> int:
@@ -52,7 +53,20 @@ class InputBatch:
         self.generators: Dict[int, Any] = {}
         self.pooling_params: Dict[str, Any] = {}
         self.vocab_size = vocab_size
-        self.sampling_metadata = SamplingMetadata()
+        self.temperature_cpu = np.full(max_num_reqs, -1.0, dtype=np.float32)     # -1: greedy (vLLM's GREEDY_TEMPERATURE)
+        self.device = "cpu"
+        self.extra_sampling = {}           # tests set metadata fields vLLM would fill from SamplingParams (e.g. min_tokens)
+
+    @property
+    def sampling_metadata(self) -> SamplingMetadata:
+        """What _make_sampling_metadata builds for the current batch."""
+        n = len(self.req_ids)
+        t = self.temperature_cpu[:n]
+        all_greedy = bool((t < 0).all())
+        kw = dict(temperature=None if all_greedy else torch.from_numpy(t.copy()).to(self.device), all_greedy=all_greedy,
+                  all_random=bool((t >= 0).all()) and n > 0, generators=self.generators, logit_bias=[None] * n)
+        kw.update(self.extra_sampling)
+        return SamplingMetadata(**kw)
 
     def add(self, st: CachedRequestState) -> None:
         i = len(self.req_ids)
@@ -65,21 +79,48 @@ class InputBatch:
         self.num_computed_tokens_cpu[i] = st.num_computed_tokens
         self.block_table[i, :len(st.block_ids)] = st.block_ids
         self.num_blocks[i] = len(st.block_ids)
+        sp = st.sampling_params
+        temp = float(getattr(sp, "temperature", 0.0) or 0.0)
+        self.temperature_cpu[i] = temp if temp > 0 else -1.0
+        self.generators.pop(i, None)
+        if temp > 0 and getattr(sp, "seed", None) is not None:
+            g = getattr(st, "generator", None)        # a resumed request keeps its generator
+            if g is None:
+                g = st.generator = torch.Generator(device=self.device).manual_seed(int(sp.seed))
+            self.generators[i] = g
 
     def remove(self, req_id: str) -> None:
         """Drops a request and closes the gap (vLLM condenses the batch the same way: rows move up)."""
         i = self.req_id_to_index.pop(req_id)
         last = len(self.req_ids) - 1
         for arr in (self.token_ids_cpu, self.num_tokens, self.num_tokens_no_spec, self.num_prompt_tokens,
-                    self.num_computed_tokens_cpu, self.block_table, self.num_blocks):
+                    self.num_computed_tokens_cpu, self.block_table, self.num_blocks, self.temperature_cpu):
             arr[i:last] = arr[i + 1:last + 1]
+        self.generators = {(k if k < i else k - 1): g for k, g in self.generators.items() if k != i}
         del self.req_ids[i]
         self.req_id_to_index = {r: k for k, r in enumerate(self.req_ids)}
 
 
 class Sampler(torch.nn.Module):
+    """Greedy rows: arg-max.  Random rows: softmax(logits / T) sampled as probs.div_(q).argmax() with q ~ Exp(1) — one
+    [B, V] exponential_ from the default generator, rows of seeded requests re-drawn with their own generator."""
+    calls = 0
+
     def forward(self, logits, sampling_metadata):
-        return SamplerOutput(sampled_token_ids=logits.argmax(dim=-1, keepdim=True).to(torch.int32), logprobs_tensors=None)
+        Sampler.calls += 1
+        sm = sampling_metadata
+        greedy = logits.argmax(dim=-1)
+        if sm.all_greedy:
+            return SamplerOutput(sampled_token_ids=greedy.view(-1, 1).to(torch.int32), logprobs_tensors=None)
+        temp = sm.temperature.to(logits.device)
+        probs = torch.softmax(logits.float() / torch.where(temp < 0, torch.ones_like(temp), temp).unsqueeze(1), dim=-1)
+        q = torch.empty_like(probs)
+        q.exponential_()
+        for i, g in sm.generators.items():
+            q[i].exponential_(generator=g)
+        rand = probs.div_(q).argmax(dim=-1)
+        out = torch.where(temp < 0, greedy, rand)
+        return SamplerOutput(sampled_token_ids=out.view(-1, 1).to(torch.int32), logprobs_tensors=None)
 
 
 class GPUModelRunner:
@@ -109,6 +150,7 @@ class GPUModelRunner:
         self.requests: Dict[str, CachedRequestState] = {}
         max_blocks = (self.max_model_len + self.block_size - 1) // self.block_size + 4
         self.input_batch = InputBatch(self.max_num_reqs, self.max_model_len, max_blocks, self.model_config.get_vocab_size())
+        self.input_batch.device = self.device
         self.sampler = Sampler()
         self.kv_caches: List[torch.Tensor] = []
         self.dummy_runs: List[tuple] = []      # (num_tokens, which model, tp world size, is_profile) — tests read it
@@ -131,7 +173,8 @@ class GPUModelRunner:
             if rid not in scheduler_output.num_scheduled_tokens:
                 ib.remove(rid)
         for new in scheduler_output.scheduled_new_reqs:
-            st = CachedRequestState(new.req_id, list(new.prompt_token_ids), list(new.block_ids), new.num_computed_tokens)
+            st = CachedRequestState(new.req_id, list(new.prompt_token_ids), list(new.block_ids), new.num_computed_tokens,
+                                    sampling_params=getattr(new, "sampling_params", None))
             self.requests[new.req_id] = st
             ib.add(st)
         for c in scheduler_output.scheduled_cached_reqs:

@@ -201,3 +201,34 @@ def test_lstm_family_speculator_by_method():
         lstm_family_speculator(LSTMSpeculatorConfig(inner_dim="512", emb_dim="256", proj_dim="512", method="sum_rnn", **base))
     with pytest.raises(ValueError, match="unknown speculator method"):
         lstm_family_speculator(LSTMSpeculatorConfig(inner_dim="512", emb_dim="512", proj_dim="512", method="sum_gru", **base))
+
+
+def test_hip_acceptance_gate_reads_vllm_sampling_metadata_field_by_field():
+    """vLLM 0.9.2's InputBatch always passes logit_bias = [None] * num_reqs (a non-empty list) — the gate
+    must look inside it; min_tokens and min_p keep a batch on vLLM's sampler; temperature-only batches are "random"."""
+    from types import SimpleNamespace as NS
+    import torch
+    from arcticinference_amd.vllm_plugin.runner_logic import hip_acceptance_kind
+
+    def sm(**kw):
+        base = dict(temperature=None, all_greedy=True, all_random=False, top_p=None, top_k=None, min_p=None, generators={},
+                    max_num_logprobs=None, no_penalties=True, min_tokens={}, logit_bias=[None, None, None],
+                    allowed_token_ids_mask=None, bad_words_token_ids={})
+        base.update(kw)
+        return NS(**base)
+
+    assert hip_acceptance_kind(sm()) == "greedy"                                  # the list of Nones is "no bias"
+    assert hip_acceptance_kind(sm(logit_bias=[None, {7: 2.0}, None])) is None
+    assert hip_acceptance_kind(sm(logit_bias=[None, {}, None])) == "greedy"
+    assert hip_acceptance_kind(sm(min_tokens={1: (5, {2})})) is None              # EOS must stay masked until min_tokens
+    assert hip_acceptance_kind(sm(min_p=torch.tensor([0.0, 0.1, 0.0]))) is None
+    assert hip_acceptance_kind(sm(max_num_logprobs=0)) is None
+    assert hip_acceptance_kind(sm(no_penalties=False)) is None
+    assert hip_acceptance_kind(sm(bad_words_token_ids={0: [[3]]})) is None
+    assert hip_acceptance_kind(sm(allowed_token_ids_mask=torch.zeros(3, 8, dtype=torch.bool))) is None
+    t = torch.tensor([-1.0, 0.8, 1.0])
+    assert hip_acceptance_kind(sm(all_greedy=False, temperature=t)) == "random"   # greedy rows mixed in
+    assert hip_acceptance_kind(sm(all_greedy=False, all_random=True, temperature=t.abs())) == "random"
+    assert hip_acceptance_kind(sm(all_greedy=False, temperature=t, top_k=torch.tensor([0, 40, 0]))) is None
+    assert hip_acceptance_kind(sm(all_greedy=False, temperature=t, top_p=torch.tensor([1.0, 0.9, 1.0]))) is None
+    assert hip_acceptance_kind(sm(all_greedy=False, temperature=None)) is None

@@ -285,3 +285,102 @@ def test_sp2_shift_on_the_gpu_matches_single_process():
             assert np.allclose(a, b, atol=3e-2, rtol=3e-2), (rank, np.abs(a - b).max())
         # 5 decode steps x 2 layers on the HIP kernel in shift mode; the prefill (192 tokens) on vLLM's backend in SP mode
         assert calls["verify"] == 10 and calls["fallback"] == 2, calls
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# random-sampling acceptance on the product path
+# ---------------------------------------------------------------------------------------------------------------
+class SoftSteered(Steered):
+    """Flattens the toy model's logits and plants the stream's token (logit 9) and one distractor (logit 8) on every
+    sampled row: a temperature-1 request then emits the stream's token with p ~ 0.6, so drafts are accepted AND rejected."""
+
+    def __call__(self, hidden_states, logits):
+        self.hidden = hidden_states
+        lg = logits.float()
+        lg = (lg - lg.mean(dim=-1, keepdim=True)) / lg.std(dim=-1, keepdim=True) * 0.1
+        rows = torch.arange(len(self.rows), device=lg.device)
+        tok = torch.tensor([int(self.streams[rid][p + 1]) for rid, p in self.rows], device=lg.device)
+        lg[rows, (tok + 977) % lg.shape[1]] = 8.0
+        lg[rows, tok] = 9.0
+        self.logits = lg.to(torch.bfloat16)
+        return self.logits
+
+
+def test_mixed_greedy_and_random_batches_are_accepted_by_the_hip_kernel(stub_vllm):
+    """Requests with a temperature (seeded) next to greedy ones, suffix drafts to verify: every verify step goes through
+    aic_rejection_random (the stand-in's RejectionSampler is never reached; the bonus token is vLLM's sampler's, as in
+    the reference, model_runner.py:394-411).  The emitted tokens must equal oracle.rejection_random fed the SAME draws:
+    twin generators with the requests' seeds replay the calls of the step in order (sampler noise, uniforms, recovery
+    noise — a request without draft tokens draws no uniforms and no recovery noise)."""
+    from oracle import spec_oracle as O
+    H.load_plugin()
+    from vllm.config import SpeculativeConfig, set_current_vllm_config
+    from vllm.v1.sample.rejection_sampler import RejectionSampler
+    from vllm.v1.worker.gpu_model_runner import GPUModelRunner, Sampler
+    spec = SpeculativeConfig(method="suffix")
+    spec.proposal_indexing = "single_advance"           # long drafts, so that several positions per request are verified
+    cfg = _vllm_config(spec)
+    H.init_single_process_groups(cfg)
+    runner = GPUModelRunner(cfg, torch.device(DEV))
+    set_current_vllm_config(cfg)
+    runner.load_model()
+    runner.initialize_kv_cache((200, torch.bfloat16))
+    B, PL, V = 4, 96, 2000
+    streams = _requests(B, PL, seed=6)
+    temps = {"r0": None, "r1": (1.0, 101), "r2": (0.7, 102), "r3": None}
+    sched = H.MiniScheduler(16, 400)
+    for rid, s in streams.items():
+        sched.add(rid, [int(x) for x in s[:PL]], *(temps[rid] or ()))
+    steer = SoftSteered(runner, sched, streams)
+    twins = {rid: torch.Generator(device=DEV).manual_seed(t[1]) for rid, t in temps.items() if t}
+    RejectionSampler.calls = Sampler.calls = 0
+    verify_steps = accepted_random = recovered_random = 0
+    for step in range(40):
+        so = sched.schedule()
+        steer.plan(so)
+        out = runner.execute_model(so)
+        ids = list(out.req_ids)
+        n = [len(so.scheduled_spec_decode_tokens.get(rid, ())) for rid in ids]
+        lg = steer.logits                                   # [sum(n_i + 1), V] rows of the step, request by request
+        temp = [temps[rid][0] if temps[rid] else -1.0 for rid in ids]
+        # (1) the sampler on the bonus rows: greedy rows arg-max, random rows softmax(l / T) / Exp(1) noise
+        bonus_rows = np.cumsum(np.asarray(n) + 1) - 1
+        bonus = []
+        for i, rid in enumerate(ids):
+            row = lg[bonus_rows[i]].float()
+            if temps[rid] is None:
+                bonus.append(int(row.argmax()))
+            else:
+                q = torch.empty(V, dtype=torch.float32, device=DEV).exponential_(generator=twins[rid])
+                bonus.append(int((torch.softmax(row / temp[i], dim=-1) / q).argmax()))
+        if sum(n) == 0:
+            want = [[b] for b in bonus]
+        else:
+            verify_steps += 1
+            # (2) uniforms, (3) recovery noise — only for requests that have draft tokens
+            u = np.zeros(sum(n))
+            noise = torch.ones(len(ids), V)
+            at = 0
+            for i, rid in enumerate(ids):
+                if n[i] and rid in twins:
+                    u[at:at + n[i]] = torch.empty(n[i], dtype=torch.float64, device=DEV).uniform_(generator=twins[rid]).cpu().numpy()
+                at += n[i]
+            for i, rid in enumerate(ids):
+                if n[i] and rid in twins:
+                    noise[i] = torch.empty(V, dtype=torch.float32, device=DEV).exponential_(generator=twins[rid]).cpu()
+            is_bonus = np.zeros(lg.shape[0], dtype=bool)
+            is_bonus[bonus_rows] = True
+            target = lg[torch.from_numpy(np.nonzero(~is_bonus)[0]).to(DEV)].cpu()
+            drafts = [t for rid in ids for t in so.scheduled_spec_decode_tokens.get(rid, ())]
+            mat = O.rejection_random(target, drafts, n, bonus, max(n), temp, u, noise)
+            want = [[int(t) for t in row if t != -1] for row in mat]
+            for i, rid in enumerate(ids):
+                if rid in twins and n[i]:
+                    acc = sum(1 for p in range(min(n[i], len(want[i]))) if want[i][p] == so.scheduled_spec_decode_tokens[rid][p])
+                    accepted_random += acc
+                    recovered_random += acc < n[i]
+        emitted = sched.update(out)
+        assert [emitted[rid] for rid in ids] == want, (step, emitted, want)
+    assert verify_steps > 10 and accepted_random > 5 and recovered_random > 3, (verify_steps, accepted_random, recovered_random)
+    assert RejectionSampler.calls == 0, "a temperature-only batch reached vLLM's RejectionSampler"
+    assert Sampler.calls == 40                          # one sampler call per step: the bonus / only token

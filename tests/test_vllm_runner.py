@@ -26,11 +26,12 @@ def build_runner(device="cpu", spec=None, dtype=torch.float32, parallel=None, ma
     return runner
 
 
-def drive(runner, prompts, steps, chunk=None, late=None, finish_at=None):
-    """Runs `steps` engine steps; returns [(emitted tokens per request, spec tokens per request)] per step."""
+def drive(runner, prompts, steps, chunk=None, late=None, finish_at=None, sampling=None):
+    """Runs `steps` engine steps; returns [(emitted tokens per request, spec tokens per request)] per step.
+    `sampling`: {req_id: (temperature, seed)} for requests that sample randomly."""
     sched = H.MiniScheduler(16, runner.max_model_len, chunk=chunk)
     for rid, p in prompts.items():
-        sched.add(rid, p)
+        sched.add(rid, p, *(sampling or {}).get(rid, ()))
     trace = []
     for step in range(steps):
         if late and step == late[0]:
@@ -74,6 +75,27 @@ def test_patched_runner_keeps_vllms_own_speculative_methods_working(stub_vllm):
     from vllm.config import SpeculativeConfig
     got, s1 = drive(build_runner(spec=SpeculativeConfig(method="ngram", num_speculative_tokens=2)), P, 8)
     assert got == want and s1.stats == s0.stats
+
+
+def test_patched_step_equals_stock_step_for_random_sampling_requests(stub_vllm):
+    """Seeded temperature sampling next to greedy requests, with drafts to verify ("ngram"): on CPU tensors the patched
+    step keeps vLLM's sampler + RejectionSampler and must consume the requests' generators exactly as the stock step does
+    (same tokens).  The sampling metadata is what vLLM's InputBatch builds (logit_bias = [None] * num_reqs)."""
+    from vllm.config import SpeculativeConfig
+    P = prompts_for(5, 4)
+    sampling = {"r1": (0.9, 11), "r3": (1.3, 12)}
+    want, s0 = drive(build_runner(spec=SpeculativeConfig(method="ngram", num_speculative_tokens=2)), P, 10, sampling=sampling)
+    assert s0.stats["drafts"] > 0
+    H.install()
+    H.load_plugin()
+    from vllm.config import SpeculativeConfig
+    r = build_runner(spec=SpeculativeConfig(method="ngram", num_speculative_tokens=2))
+    got, s1 = drive(r, P, 10, sampling=sampling)
+    assert got == want and s1.stats == s0.stats
+    sm = r.input_batch.sampling_metadata
+    assert not sm.all_greedy and sm.logit_bias == [None] * 4 and set(sm.generators) == {1, 3}
+    greedy, _ = drive(build_runner(spec=SpeculativeConfig(method="ngram", num_speculative_tokens=2)), P, 10)
+    assert greedy != got, "the random requests must actually sample"
 
 
 def test_runner_construction_rules(stub_vllm):

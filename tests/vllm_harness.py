@@ -75,8 +75,10 @@ class MiniScheduler:
         self.next_block = 1            # block 0 stays unused (vLLM's null block)
         self.stats = dict(drafts=0, draft_tokens=0, accepted=0)
 
-    def add(self, req_id: str, prompt: List[int]) -> None:
-        self.reqs[req_id] = dict(prompt=list(prompt), out=[], computed=0, spec=[], blocks=[], sent=False)
+    def add(self, req_id: str, prompt: List[int], temperature: float = 0.0, seed: Optional[int] = None) -> None:
+        from types import SimpleNamespace
+        self.reqs[req_id] = dict(prompt=list(prompt), out=[], computed=0, spec=[], blocks=[], sent=False,
+                                 sampling=SimpleNamespace(temperature=temperature, seed=seed))
         self.new.append(req_id)
 
     def finish(self, req_id: str) -> None:
@@ -103,7 +105,7 @@ class MiniScheduler:
             if r["spec"]:
                 spec[rid] = list(r["spec"])
             if not r["sent"]:
-                new.append(NewRequestData(rid, list(r["prompt"]), list(r["blocks"]), r["computed"]))
+                new.append(NewRequestData(rid, list(r["prompt"]), list(r["blocks"]), r["computed"], r["sampling"]))
                 r["sent"] = True
             else:
                 cached.append(CachedRequestData(rid, False, [], fresh, r["computed"]))
