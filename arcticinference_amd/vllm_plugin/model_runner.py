@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import contextlib
 import copy
+import logging
 import time
 from typing import Any, List, Optional
 
@@ -32,6 +33,8 @@ import torch
 from . import step_context
 from .runner_logic import (INDEXING_REFERENCE, MAX_SPEC_LEN, arctic_max_spec_tokens, hip_acceptance_kind, merge_proposals,
                            min_suffix_score, proposal_end_index, proposal_indexing, rewrite_sampled, suffix_query)
+
+logger = logging.getLogger(__name__)
 
 ARCTIC_METHODS = ("arctic", "suffix", "mlp_speculator")
 
@@ -166,7 +169,12 @@ def build_bootstrap_patches():
         _orig_init = WorkerBase.__init__
 
         def __init__(self, *args, **kwargs):
-            # the runner patch touches the GPU runtime: applied in the worker, after the fork (plugins.py:54-63)
+            # the runner patch touches the GPU runtime: applied in the worker, after the fork (plugins.py:54-63); this is
+            # also the first place the native library is loaded and asked for a device
+            from .. import _native
+            if _native.lib().aic_device_count() <= 0:
+                logger.warning("ArcticInference (MI355X build): no HIP device visible in this worker; kernels will refuse "
+                               "to run (AIC_ERR_NO_DEVICE)")
             patch = build_model_runner_patch()
             from vllm.v1.worker.gpu_model_runner import GPUModelRunner
             if "execute_model" not in vars(GPUModelRunner).get("_arctic_patches", {}):

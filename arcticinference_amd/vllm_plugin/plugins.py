@@ -31,12 +31,13 @@ def arctic_inference_plugin() -> None:
     if os.getenv("VLLM_USE_V1") == "0":
         logger.warning("ArcticInference only supports vLLM V1, but detected V0 engine. Ignoring plugin!")
         return
+    # Nothing here may touch the HIP runtime: vLLM loads general plugins in the API-server and EngineCore processes too,
+    # which later FORK the workers, and a child of a HIP-initialised parent cannot use the GPU (the reference defers
+    # everything GPU-side to WorkerBasePatch for the same reason, plugins.py:54-63).  Only the file's presence is checked
+    # (there is no CPU fallback to degrade to); the device probe runs in the worker (model_runner.WorkerBasePatch).
     from .. import _native
-    # a missing library raises here (there is no CPU fallback to degrade to); a process without a visible GPU (vLLM's
-    # API-server front end loads general plugins too) still gets the argument / config patches — compute entry points
-    # answer AIC_ERR_NO_DEVICE there
-    if _native.lib().aic_device_count() <= 0:
-        logger.warning("ArcticInference (MI355X build): no HIP device visible in this process; kernels will refuse to run")
+    if not os.path.exists(_native.LIB_PATH):
+        raise ImportError(f"{_native.LIB_PATH} is missing: build it with `make -C {_native.CSRC}`; there is no fallback")
 
     # SwiftKV: HF config type + model class (plugins.py:86-98); the class is resolved from its "module:Class" string on
     # first use, so vLLM's model zoo is not imported here
@@ -57,12 +58,13 @@ def arctic_inference_plugin() -> None:
 
     from .args import build_args_patches
     from .config import build_config_patches
+    from .custom_ops import build_compilation_patches
     from .model_runner import build_bootstrap_patches
     from .stats import build_stats_patches
     from .ulysses import build_ulysses_patches
 
     # same order as the reference (plugins.py:111-126): bootstrap, arguments / configs / stats, then the Ulysses set.
     # The GPUModelRunner patch is applied by WorkerBasePatch inside each worker, after the fork.
-    for patch in (build_bootstrap_patches() + build_args_patches() + build_config_patches() + build_stats_patches() +
-                  build_ulysses_patches()):
+    for patch in (build_bootstrap_patches() + build_args_patches() + build_config_patches() + build_compilation_patches() +
+                  build_stats_patches() + build_ulysses_patches()):
         patch.apply_patch()

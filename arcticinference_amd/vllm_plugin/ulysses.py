@@ -56,6 +56,7 @@ def build_ulysses_patches():
 
     from .. import ops
     from ..patching import ArcticPatch
+    from .custom_ops import attention_op
     from .model_runner import is_shift_parallel_mode
 
     # -----------------------------------------------------------------------------------------------
@@ -284,6 +285,14 @@ def build_ulysses_patches():
             return out
 
         def forward(self, query, key, value, **kwargs):
+            """What Dynamo traces: one opaque op (custom_ops.py).  Layers called with extra arguments (MLA's output_shape)
+            are not served by the route and keep the direct call."""
+            if kwargs or not getattr(self, "layer_name", None):
+                return self._arctic_forward(query, key, value, **kwargs)
+            return attention_op()(query, key, value, self.layer_name)
+
+        def _arctic_forward(self, query, key, value, **kwargs):
+            """The eager body behind the op: head repartition around attention (ulysses.py:457-519) + the verify route."""
             if self.sp_size == 1 or is_shift_parallel_mode():
                 return self._arctic_attend(query, key, value, **kwargs)
             ua = self._ulysses

@@ -27,6 +27,15 @@ class CompilationConfig:
     inductor_compile_config: dict = field(default_factory=dict)
     static_forward_context: dict = field(default_factory=dict)
     full_cuda_graph: bool = False
+    splitting_ops: list = field(default_factory=list)
+
+    def set_splitting_ops_for_v1(self):
+        """The ops vLLM cuts its piecewise graphs at (attention runs eagerly between the captured pieces)."""
+        if self.splitting_ops and self.full_cuda_graph:
+            raise ValueError("full_cuda_graph cannot be used together with splitting_ops")
+        if not self.splitting_ops:
+            self.splitting_ops = [] if self.full_cuda_graph else ["vllm.unified_attention",
+                                                                   "vllm.unified_attention_with_output"]
 
 
 @dataclass
@@ -158,6 +167,9 @@ class VllmConfig:
     device_config: DeviceConfig = field(default_factory=DeviceConfig)
     load_config: LoadConfig = field(default_factory=LoadConfig)
     quant_config: Any = None
+
+    def __post_init__(self):
+        self.compilation_config.set_splitting_ops_for_v1()
 
     def __str__(self):
         return f"model={self.model_config.hf_config.model_type}, tensor_parallel_size={self.parallel_config.tensor_parallel_size}"

@@ -9,6 +9,7 @@ class ForwardContext:
     virtual_engine: int = 0
     num_tokens: Optional[int] = None
     skip_cuda_graphs: bool = False
+    no_compile_layers: dict = None        # layer name -> module (vLLM: compilation_config.static_forward_context)
 
 
 _ctx: Optional[ForwardContext] = None
@@ -25,7 +26,8 @@ def set_forward_context(attn_metadata, vllm_config, virtual_engine: int = 0, num
                         skip_cuda_graphs: bool = False):
     global _ctx
     prev = _ctx
-    _ctx = ForwardContext(attn_metadata, virtual_engine, num_tokens, skip_cuda_graphs)
+    _ctx = ForwardContext(attn_metadata, virtual_engine, num_tokens, skip_cuda_graphs,
+                          vllm_config.compilation_config.static_forward_context)
     history.append((num_tokens, skip_cuda_graphs))
     try:
         yield

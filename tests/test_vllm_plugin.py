@@ -3,6 +3,7 @@
 patched GPUModelRunner.execute_model driven by a minimal scheduler.  The HIP routes need a GPU
 (tests/test_vllm_plugin_gpu.py); here attention and acceptance stay on the stand-in's torch implementations, which is
 exactly the path the plugin takes for tensors that are not on the device."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -19,6 +20,7 @@ PATCHED = {
     "vllm.config:ParallelConfig": ["__new__"],
     "vllm.config:SpeculativeConfig": ["__new__", "__post_init__", "from_dict"],
     "vllm.config:VllmConfig": ["__str__"],
+    "vllm.config:CompilationConfig": ["set_splitting_ops_for_v1"],      # this build's addition (vllm_plugin/custom_ops.py)
     "vllm.transformers_utils.configs.mlp_speculator:MLPSpeculatorConfig": ["__init__"],
     "vllm.v1.spec_decode.metrics:SpecDecodingStats": ["observe_draft"],
     "vllm.v1.spec_decode.metrics:SpecDecodingLogging": ["log"],
@@ -224,3 +226,27 @@ def test_piecewise_interpreter_patch(stub_vllm):
     pb = gm.__dict__["submod_0"]
     assert pb.sym_shape_indices == [0, 2] and Backend.compiler_manager.seen == (0, 1, None)
     assert compilation_counter.num_piecewise_capturable_graphs_seen == before + 1
+
+
+def test_plugin_loader_leaves_the_gpu_runtime_alone_until_the_worker():
+    """general plugins are loaded in vLLM's API-server / EngineCore parents, which fork the workers — the
+    loader may not initialise (or even load) the HIP library; the worker-side patch does (reference plugins.py:54-63)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, os\n"
+        f"sys.path[:0] = [{os.path.dirname(os.path.abspath(__file__))!r}, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}]\n"
+        "import vllm_harness as H\n"
+        "H.install()\n"
+        "from arcticinference_amd import _native\n"
+        "H.load_plugin(worker=False)\n"
+        "assert _native._lib is None, 'the plugin loader opened libarctic_hip.so'\n"
+        "from vllm.engine.arg_utils import EngineArgs\n"
+        "assert '_arctic_patches' in vars(EngineArgs)\n"
+        "from vllm.config import VllmConfig\n"
+        "from vllm.v1.worker.worker_base import WorkerBase\n"
+        "WorkerBase(VllmConfig())\n"
+        "assert _native._lib is not None, 'the worker patch must load the library and probe the device'\n"
+        "print('ok')\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
