@@ -1644,11 +1644,22 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
 // whose SHAPE (which kernel at which position) repeats from step to step while grids and arguments change, so the chain is
 // kept as an instantiated HIP graph per shape and each step only rewrites the kernel nodes' parameters
 // (hipGraphExecKernelNodeSetParams, ~0.7 us per node) and launches it once.
+// An instantiated graph may still be in flight when the next call of the same shape arrives (interleaved lanes enqueue
+// one lane's step while the other's runs), and rewriting the node parameters of an exec whose launch has not finished is
+// not something the runtime promises to keep apart: every shape therefore owns a few execs, each followed by an event,
+// and a call takes one whose last launch has completed (instantiating another, up to kExecsPerShape, before it waits).
+struct GraphExecSlot {
+  hipGraphExec_t exec;
+  hipEvent_t done;
+  bool launched;
+};
+constexpr size_t kExecsPerShape = 4;
 struct LayerGraph {
   int device;
   std::vector<void*> funcs;           // the shape: kernel of every node, in order
   hipGraph_t graph;
-  hipGraphExec_t exec;
+  std::vector<GraphExecSlot> execs;
+  size_t next_exec;
   std::vector<hipGraphNode_t> nodes;
   uint64_t last_use;
 };
@@ -1657,7 +1668,31 @@ static std::vector<LayerGraph> g_graphs;
 static uint64_t g_graph_tick = 0;
 static std::atomic<int> g_graph_mode{1};          // aic_debug_attn_graph: 0 = always launch kernel by kernel
 static std::atomic<unsigned> g_layers_calls{0};
-static std::atomic<uint64_t> g_graph_launches{0}, g_graph_builds{0};
+static std::atomic<uint64_t> g_graph_launches{0}, g_graph_builds{0}, g_graph_execs{0};
+
+static void destroy_layer_graph(LayerGraph& c) {
+  for (GraphExecSlot& e : c.execs) {
+    if (e.launched) (void)hipEventSynchronize(e.done);
+    (void)hipGraphExecDestroy(e.exec);
+    (void)hipEventDestroy(e.done);
+  }
+  (void)hipGraphDestroy(c.graph);
+}
+
+// A fresh exec of `c`, instantiated from the graph as it stands (callers set every node's parameters right after).
+static int add_exec(LayerGraph& c) {
+  GraphExecSlot e{};
+  AIC_HIP_TRY(hipGraphInstantiate(&e.exec, c.graph, nullptr, nullptr, 0));
+  const hipError_t err = hipEventCreateWithFlags(&e.done, hipEventDisableTiming);
+  if (err != hipSuccess) {
+    (void)hipGraphExecDestroy(e.exec);
+    AIC_HIP_TRY(err);
+  }
+  e.launched = false;
+  c.execs.push_back(e);
+  g_graph_execs.fetch_add(1, std::memory_order_relaxed);
+  return AIC_OK;
+}
 constexpr size_t kMaxLayerGraphs = 24;
 
 static int replay_as_graph(const Recorder& rec, hipStream_t s) {
@@ -1694,12 +1729,12 @@ static int replay_as_graph(const Recorder& rec, hipStream_t s) {
       size_t victim = 0;
       for (size_t i = 1; i < g_graphs.size(); ++i)
         if (g_graphs[i].last_use < g_graphs[victim].last_use) victim = i;
-      (void)hipGraphExecDestroy(g_graphs[victim].exec);
-      (void)hipGraphDestroy(g_graphs[victim].graph);
+      destroy_layer_graph(g_graphs[victim]);
       g_graphs.erase(g_graphs.begin() + static_cast<long>(victim));
     }
     LayerGraph c;
     c.device = device;
+    c.next_exec = 0;
     c.nodes.resize(n);
     AIC_HIP_TRY(hipGraphCreate(&c.graph, 0));
     for (size_t i = 0; i < n; ++i) {
@@ -1710,19 +1745,42 @@ static int replay_as_graph(const Recorder& rec, hipStream_t s) {
       }
       c.funcs.push_back(rec.recs[i].func);
     }
-    const hipError_t e = hipGraphInstantiate(&c.exec, c.graph, nullptr, nullptr, 0);
-    if (e != hipSuccess) {
+    const int rc = add_exec(c);
+    if (rc != AIC_OK) {
       (void)hipGraphDestroy(c.graph);
-      AIC_HIP_TRY(e);
+      return rc;
     }
     g_graphs.push_back(std::move(c));
     g = &g_graphs.back();
     g_graph_builds.fetch_add(1, std::memory_order_relaxed);
-  } else {
-    for (size_t i = 0; i < n; ++i) AIC_HIP_TRY(hipGraphExecKernelNodeSetParams(g->exec, g->nodes[i], &kp[i]));
   }
+  // an exec whose previous launch has finished (round robin from the one after the last used)
+  GraphExecSlot* slot = nullptr;
+  for (size_t k = 0; k < g->execs.size() && !slot; ++k) {
+    GraphExecSlot& e = g->execs[(g->next_exec + k) % g->execs.size()];
+    if (!e.launched || hipEventQuery(e.done) == hipSuccess) {
+      slot = &e;
+      g->next_exec = (g->next_exec + k + 1) % g->execs.size();
+    }
+  }
+  (void)hipGetLastError();                        // a "not ready" answer above is not an error of this call
+  if (!slot) {
+    if (g->execs.size() < kExecsPerShape) {
+      const int rc = add_exec(*g);
+      if (rc != AIC_OK) return rc;
+      slot = &g->execs.back();
+      g->next_exec = 0;
+    } else {                                      // every exec busy: wait for the oldest
+      slot = &g->execs[g->next_exec];
+      g->next_exec = (g->next_exec + 1) % g->execs.size();
+      AIC_HIP_TRY(hipEventSynchronize(slot->done));
+    }
+  }
+  for (size_t i = 0; i < n; ++i) AIC_HIP_TRY(hipGraphExecKernelNodeSetParams(slot->exec, g->nodes[i], &kp[i]));
   g->last_use = ++g_graph_tick;
-  AIC_HIP_TRY(hipGraphLaunch(g->exec, s));
+  AIC_HIP_TRY(hipGraphLaunch(slot->exec, s));
+  AIC_HIP_TRY(hipEventRecord(slot->done, s));
+  slot->launched = true;
   g_graph_launches.fetch_add(1, std::memory_order_relaxed);
   return AIC_OK;
 }

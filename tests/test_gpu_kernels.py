@@ -464,6 +464,57 @@ def test_verify_attention_layers_graph_equals_kernel_launches():
         lib.aic_debug_attn_graph(1)
 
 
+def test_verify_attention_layers_graph_back_to_back_calls_keep_their_own_parameters():
+    """interleaved lanes enqueue a same-shape call while the previous one is still running.  Calls of one
+    shape with different geometry, queries and caches go out back to back WITHOUT a sync in between (several more than
+    the per-shape exec pool holds); every call's output must be bit-identical to its kernel-by-kernel result — a call
+    must never see the node parameters of the call behind it."""
+    from arcticinference_amd import _native as N
+    D, Hq, Hkv, L, B = 128, 32, 8, 6, 16
+    ops = _ops()
+    lib = N.lib()
+    g = torch.Generator().manual_seed(5)
+    calls = []
+    for c in range(7):
+        q_lens = [int(x) for x in torch.randint(1, 5, (B,), generator=g)]
+        q_lens[c % B] = 33                                   # one long draft: the one-grid launch + combine (same shape)
+        ctxs = [int(x) for x in torch.randint(2500, 4000, (B,), generator=g)]
+        q, kc, vc, bt, qsl = _attn_case(B, Hq, Hkv, D, q_lens, ctxs, 16, seed=40 + c)
+        dq = q.to(DEV)
+        calls.append(dict(q_lens=q_lens, ctxs=ctxs, qs=torch.stack([dq * (1.0 + 0.5 * l) for l in range(L)]).contiguous(),
+                          k=kc.to(DEV), v=vc.to(DEV), bt=bt.to(DEV), seq=torch.tensor(ctxs, dtype=torch.int32, device=DEV),
+                          qsl=torch.tensor(qsl, device=DEV), rs=ops.split_requests(q_lens, Hq // Hkv, DEV)))
+
+    def issue(c, out):
+        plan = ops.VerifyAttentionPlan(c["qs"][0], out[0], c["k"], c["bt"], c["seq"], c["qsl"], max(c["q_lens"]),
+                                       max(c["ctxs"]), D ** -0.5, req_split=c["rs"])
+        a = plan._args
+        kt, vt, n, keep = plan.layer_tables([c["k"]] * L, [c["v"]] * L)
+        N.check(lib.aic_verify_attention_layers(a[0], a[1], c["qs"].stride(0), kt, vt, n, *a[4:20], a[20], a[21],
+                                                out.stride(0), *a[22:]))
+        return plan, keep
+
+    try:
+        want = []
+        lib.aic_debug_attn_graph(0)
+        for c in calls:
+            out = torch.full_like(c["qs"], float("nan"))
+            issue(c, out)
+            torch.cuda.synchronize()
+            want.append(out)
+        lib.aic_debug_attn_graph(1)
+        l0, _ = N.attn_graph_stats()
+        outs = [torch.full_like(c["qs"], float("nan")) for c in calls]
+        torch.cuda.synchronize()
+        keep = [issue(c, o) for c, o in zip(calls, outs)]      # seven same-shape graph launches in flight, no sync
+        torch.cuda.synchronize()
+        assert N.attn_graph_stats()[0] - l0 == len(calls)
+        for i, (o, w) in enumerate(zip(outs, want)):
+            assert torch.equal(o, w), i
+    finally:
+        lib.aic_debug_attn_graph(1)
+
+
 def test_verify_attention_unsupported_shapes():
     from arcticinference_amd._native import NativeError
     q, kc, vc, bt, qsl = _attn_case(1, 4, 1, 96, [2], [40], 16, seed=1)
