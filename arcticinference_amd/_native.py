@@ -129,6 +129,10 @@ _SIGNATURES = {
                                         c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_float, c_void_p, c_int64, c_void_p, c_size_t, c_int, c_void_p, c_int,
                                         c_void_p, c_int, c_void_p]),
+    "aic_verify_attention_win": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
+                                         c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                         c_int, c_float, c_void_p, c_int64, c_void_p, c_size_t, c_int, c_void_p, c_int,
+                                         c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "aic_ulysses_pack_qkv": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int,
                                      c_int, c_int, c_void_p]),
     "aic_ulysses_split_qkv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

@@ -89,7 +89,20 @@ struct AttnParams {
   int light_first;
   int light_stride;
   int light_pct;
+  // gpt-oss layers.  window > 0: query position p sees keys p - window + 1 .. p only — the token range of a request starts
+  // at the tile that holds key (ctx - q_len) - window + 1 instead of at 0, and the lower bound joins the causal mask.
+  // sinks (f32 [Hq], may be null): one extra logit per head in the soft-max normalisation, no value — it is the initial
+  // (max, sum = 1) state of the FIRST partial of every row, so it is counted once however the range is split.
+  int window;
+  const float* sinks;
 };
+
+// first token of the range a request's rows can see, rounded down to a tile (0 without a window)
+__device__ __forceinline__ int window_begin(const AttnParams& P, int ctx, int q_len) {
+  if (P.window <= 0) return 0;
+  const int lo = ctx - q_len - P.window + 1;
+  return lo > 0 ? (lo & ~(kTile - 1)) : 0;
+}
 
 // 16-byte load of KV bytes, non-temporal: every byte of the cache is read once per call, and with the default
 // policy the stream evicts itself through the L2 (measured on the B = 64 x 4096-token case: 190.7 -> 171.0 us per
@@ -122,7 +135,7 @@ __device__ __forceinline__ int v_tile_off(int t, int ch) {
 // bounds the long-draft kernel.  Produces P as bf16 head + tail fragments (B operand of O^T = V^T P^T).
 template <int DT>
 __device__ __forceinline__ void softmax_tile(const f32x4& s0, const f32x4& s1, bool need_mask, bool row_ok, int tt,
-                                             int g, int t_end, int limit, float scale_log2, float& m_run,
+                                             int g, int t_end, int limit, int wnd, float scale_log2, float& m_run,
                                              float& l_run, f32x4 (&o)[DT], bf16x8& pf, bf16x8& pl) {
   float sc[8];
 #pragma unroll
@@ -136,7 +149,7 @@ __device__ __forceinline__ void softmax_tile(const f32x4& s0, const f32x4& s1, b
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int tok = tt + 16 * th + 4 * g + e;
-        if (!(row_ok && tok < t_end && tok <= limit)) sc[th * 4 + e] = -INFINITY;
+        if (!(row_ok && tok < t_end && tok <= limit && tok > limit - wnd)) sc[th * 4 + e] = -INFINITY;
       }
   }
   float tmax = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
@@ -343,11 +356,13 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
 
   const int n_parts = P.n_splits * R;
   const int part = by * R + range;
-  const int tiles_total = (ctx + kTile - 1) / kTile;
+  const int t_lo = window_begin(P, ctx, q_len);           // 0 unless the layer has a sliding window
+  const int wnd = P.window > 0 ? P.window : (1 << 30);
+  const int tiles_total = (ctx - t_lo + kTile - 1) / kTile;
   int t_begin, t_end;
   if (P.light_pct == 100) {
     const int tiles_per_part = (tiles_total + n_parts - 1) / n_parts;
-    t_begin = part * tiles_per_part * kTile;
+    t_begin = t_lo + part * tiles_per_part * kTile;
     t_end = min(ctx, t_begin + tiles_per_part * kTile);
   } else {
     // every split of THIS item weighs light_pct if its workgroup is one of the sharing ones, else 100: cumulative
@@ -362,8 +377,8 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
       }
       w_all += w * R;
     }
-    t_begin = (tiles_total * c0 / w_all) * kTile;
-    t_end = min(ctx, (tiles_total * c1 / w_all) * kTile);
+    t_begin = t_lo + (tiles_total * c0 / w_all) * kTile;
+    t_end = min(ctx, t_lo + (tiles_total * c1 / w_all) * kTile);
   }
 
   const int64_t kv_row = static_cast<int64_t>(Hkv) * HD;  // elements between consecutive tokens of a page
@@ -398,6 +413,11 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
   for (int mt = 0; mt < MTQ; ++mt) {
     m_run[mt] = -INFINITY;
     l_run[mt] = 0.0f;
+    if (P.sinks != nullptr && part == 0) {      // the row's first partial starts from the sink: (max, sum) = (sink, 1)
+      const int rc = min(row0 + mt * 16 + c16, n_rows - 1);
+      m_run[mt] = P.sinks[h * G + (rc - (rc / G) * G)] * kLog2e;      // log2 domain, like the scaled scores
+      l_run[mt] = 1.0f;                         // (l_run is the row's sum, replicated over the row's four lanes)
+    }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) o_acc[mt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -528,10 +548,11 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
       pages_next = tile_pages(tn + kTile);
 
       bf16x8 pfrag[MTQ], pfrag_lo[MTQ];
-      const bool need_mask = tn > t_end || tn > ctx - q_len + 1;  // the tile reaches the causal edge / range end
+      // the tile reaches the causal edge / range end, or (window) lies below the last row's lower bound ctx - window
+      const bool need_mask = tn > t_end || tn > ctx - q_len + 1 || tt < ctx - wnd;
 #pragma unroll
       for (int mt = 0; mt < MTQ; ++mt) {
-        softmax_tile<DT>(st[mt][0], st[mt][1], need_mask, row_ok[mt], tt, g, t_end, ctx - q_len + row_pos[mt], scale_log2,
+        softmax_tile<DT>(st[mt][0], st[mt][1], need_mask, row_ok[mt], tt, g, t_end, ctx - q_len + row_pos[mt], wnd, scale_log2,
                      m_run[mt], l_run[mt], o_acc[mt], pfrag[mt], pfrag_lo[mt]);
       }
 
@@ -726,7 +747,7 @@ template <int NT, int RT, int D>
 __device__ __forceinline__ void long_tile_compute(const char* kb, const char* vb, const uint4 (&qf)[RT][D / 32],
                                                   const bool (&row_ok)[RT], const int (&row_pos)[RT],
                                                   float (&m_run)[RT], float (&l_run)[RT], f32x4 (&o_acc)[RT][D / 16], int tt,
-                                                  int t_end, int ctx, int q_len, float scale_log2, int g, int c16) {
+                                                  int t_end, int ctx, int q_len, int wnd, float scale_log2, int g, int c16) {
     // K fragments of the tile (A operand of S^T = K Q^T): lane (token c16 [+16], d = 32 s + 8 g)
     constexpr int DS = D / 32, DT = D / 16;   // k-steps of the score MFMAs, 16-wide output tiles
     uint4 kf[2][DS];
@@ -748,7 +769,7 @@ __device__ __forceinline__ void long_tile_compute(const char* kb, const char* vb
         for (int th = 0; th < 2; ++th)
           st[mt][th] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[th][s]),
                                                                __builtin_bit_cast(bf16x8, qf[mt][s]), st[mt][th], 0, 0, 0);
-    const bool need_mask = tt + kTile > t_end || tt + kTile > ctx - q_len + 1;
+    const bool need_mask = tt + kTile > t_end || tt + kTile > ctx - q_len + 1 || tt < ctx - wnd;
     if (need_mask) {
 #pragma unroll
       for (int mt = 0; mt < NT; ++mt) {
@@ -758,7 +779,7 @@ __device__ __forceinline__ void long_tile_compute(const char* kb, const char* vb
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int tok = tt + 16 * th + 4 * g + e;
-            if (!(row_ok[mt] && tok < t_end && tok <= limit)) st[mt][th][e] = -INFINITY;
+            if (!(row_ok[mt] && tok < t_end && tok <= limit && tok > limit - wnd)) st[mt][th][e] = -INFINITY;
           }
       }
     }
@@ -887,9 +908,11 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
   const int row_base = bz * (4 * RT * 16);
   if (row_base >= n_rows) return;
 
-  const int tiles_total = (ctx + kTile - 1) / kTile;
+  const int t_lo = window_begin(P, ctx, q_len);
+  const int wnd = P.window > 0 ? P.window : (1 << 30);
+  const int tiles_total = (ctx - t_lo + kTile - 1) / kTile;
   const int tiles_per_part = (tiles_total + P.n_splits - 1) / P.n_splits;
-  const int t_begin = by * tiles_per_part * kTile;
+  const int t_begin = t_lo + by * tiles_per_part * kTile;
   const int t_end = min(ctx, t_begin + tiles_per_part * kTile);
   const int n_iter = t_begin < t_end ? (t_end - t_begin + kTile - 1) / kTile : 0;
 
@@ -932,6 +955,11 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
   for (int mt = 0; mt < RT; ++mt) {
     m_run[mt] = -INFINITY;
     l_run[mt] = 0.0f;
+    if (P.sinks != nullptr && by == 0) {        // first partial of the row: starts from the sink
+      const int rc = min(row_base + (wave + 4 * mt) * 16 + c16, n_rows - 1);
+      m_run[mt] = P.sinks[h * G + (rc - (rc / G) * G)] * kLog2e;
+      l_run[mt] = g == 0 ? 1.0f : 0.0f;         // (here l_run is a per-lane share of the row's sum: one lane carries the 1)
+    }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) o_acc[mt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -1033,7 +1061,7 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
         const int slot = KV8 ? (it & 1) : (it & (kLongRing - 1));
         const char* kb = lds_b + kImgBase + slot * (2 * kImg);
         long_tile_compute<NT, RT, D>(kb, kb + kImg, qf, row_ok, row_pos, m_run, l_run, o_acc, t_begin + it * kTile, t_end,
-                                     ctx, q_len, scale_log2, g, c16);
+                                     ctx, q_len, wnd, scale_log2, g, c16);
       }
     }
   };
@@ -1381,7 +1409,24 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
                             int num_kv_heads, int head_size, int block_size, float sm_scale, void* out,
                             int64_t out_stride, void* workspace, size_t workspace_bytes, int max_seq_len,
                             const int32_t* short_reqs, int n_short, const int32_t* long_reqs, int n_long, void* stream) {
+  return aic_verify_attention_win(q, q_stride, k_cache, v_cache, block_stride, kv_dtype, k_scale, v_scale, block_table,
+                                  max_blocks_per_seq, seq_lens, query_start_loc, batch, num_tokens, max_q_len, num_q_heads,
+                                  num_kv_heads, head_size, block_size, sm_scale, out, out_stride, workspace, workspace_bytes,
+                                  max_seq_len, short_reqs, n_short, long_reqs, n_long, 0, nullptr, stream);
+}
+
+int aic_verify_attention_win(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
+                             int64_t block_stride, int kv_dtype, const float* k_scale, const float* v_scale,
+                             const int32_t* block_table, int max_blocks_per_seq, const int32_t* seq_lens,
+                             const int32_t* query_start_loc, int batch, int num_tokens, int max_q_len, int num_q_heads,
+                             int num_kv_heads, int head_size, int block_size, float sm_scale, void* out,
+                             int64_t out_stride, void* workspace, size_t workspace_bytes, int max_seq_len_full,
+                             const int32_t* short_reqs, int n_short, const int32_t* long_reqs, int n_long,
+                             int sliding_window, const float* sinks, void* stream) {
   if (batch == 0 || num_tokens == 0) return AIC_OK;
+  AIC_REQUIRE(sliding_window >= 0, "sliding_window must be >= 0 (0 = none)");
+  // what a request streams at most: the whole context, or — sliding window — the window plus the draft and tile slack
+  const int max_seq_len = sliding_window > 0 ? std::min(max_seq_len_full, sliding_window + max_q_len + kTile) : max_seq_len_full;
   AIC_REQUIRE(q && k_cache && v_cache && block_table && seq_lens && query_start_loc && out && workspace,
               "null pointer argument to aic_verify_attention");
   AIC_REQUIRE(batch > 0 && num_tokens > 0 && max_q_len > 0 && num_q_heads > 0 && num_kv_heads > 0 && block_size > 0 &&
@@ -1490,6 +1535,8 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
   P.light_first = 0;
   P.light_stride = 0;
   P.light_pct = 100;
+  P.window = sliding_window;
+  P.sinks = sinks;
 
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;

@@ -178,13 +178,17 @@ def verify_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
                      sm_scale: float, out: Optional[torch.Tensor] = None, num_splits_max: int = 64,
                      q_lens_host: Optional[Sequence[int]] = None, req_split=None,
                      k_scale: Optional[torch.Tensor] = None, v_scale: Optional[torch.Tensor] = None,
-                     stream: Optional[int] = None) -> torch.Tensor:
+                     stream: Optional[int] = None, sliding_window: int = 0,
+                     sinks: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q [T, Hq, D] (token stride may exceed Hq*D: a view into an all-to-all receive buffer works),
     caches [num_blocks, block_size, Hkv, D] in bf16, or float8_e4m3fn with per-tensor `k_scale` / `v_scale`
     (device scalars, the scales A16 divided by); returns [T, Hq, D].  `q_lens_host` (the per-request query
     lengths, which vLLM has on the host) lets long drafts take the shared-tile kernel.  `stream`: raw HIP stream
-    handle (default: torch's current stream; a caller that issues one call per layer looks it up once)."""
-    _need_cuda(q, k_cache, v_cache, block_table, seq_lens, query_start_loc)
+    handle (default: torch's current stream; a caller that issues one call per layer looks it up once).
+    `sliding_window` W > 0 / `sinks` f32 [Hq]: the per-layer features of gpt-oss-class models (aic_verify_attention_win)."""
+    _need_cuda(q, k_cache, v_cache, block_table, seq_lens, query_start_loc, sinks)
+    if sinks is not None and (sinks.dtype != torch.float32 or sinks.numel() != q.shape[1] or not sinks.is_contiguous()):
+        raise ValueError("sinks: contiguous float32, one value per query head")
     T, Hq, D = q.shape
     nb, bs, Hkv, D2 = k_cache.shape
     assert D == D2 and q.stride(2) == 1 and q.stride(1) == D
@@ -197,12 +201,12 @@ def verify_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     if req_split is None and q_lens_host is not None:
         req_split = split_requests(q_lens_host, Hq // Hkv, q.device)
     short, n_short, long_, n_long = req_split if req_split is not None else (None, 0, None, 0)
-    N.check(N.lib().aic_verify_attention_ex(
+    N.check(N.lib().aic_verify_attention_win(
         q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(), k_cache.stride(0), kvd, _ptr(k_scale),
         _ptr(v_scale), block_table.data_ptr(), block_table.size(1), seq_lens.data_ptr(), query_start_loc.data_ptr(), B, T,
         int(max_q_len), Hq, Hkv, D, bs, float(sm_scale), out.data_ptr(), out.stride(0), ws.data_ptr(), ws.numel(),
         int(max_seq_len), _ptr(short) if n_short else None, n_short, _ptr(long_) if n_long else None, n_long,
-        N.current_stream_ptr() if stream is None else stream))
+        int(sliding_window or 0), _ptr(sinks), N.current_stream_ptr() if stream is None else stream))
     return out
 
 

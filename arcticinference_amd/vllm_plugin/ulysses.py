@@ -243,8 +243,13 @@ def build_ulysses_patches():
             kv_cache = self.kv_cache[ctx.virtual_engine]
             if not _flash_layout(kv_cache, self.num_kv_heads, self.head_size) or self.head_size not in (64, 128):
                 return None
-            if getattr(self, "sliding_window", None) or getattr(self.impl, "alibi_slopes", None) is not None or \
-                    getattr(self.impl, "logits_soft_cap", None):
+            if getattr(self.impl, "alibi_slopes", None) is not None or getattr(self.impl, "logits_soft_cap", None):
+                return None
+            # gpt-oss-class layers: a sliding window shortens the token range, a per-head sink adds one term to the
+            # soft-max normalisation (aic_verify_attention_win)
+            window = int(getattr(self, "sliding_window", None) or 0)
+            sinks = self._arctic_sinks()
+            if sinks is False:
                 return None
             fp8 = kv_cache.dtype in (torch.uint8, torch.float8_e4m3fn)
             if fp8 and self.head_size != 128:
@@ -273,8 +278,34 @@ def build_ulysses_patches():
             ops.verify_attention(q, k_cache, v_cache, meta.block_table, meta.seq_lens.to(torch.int32),
                                  meta.query_start_loc.to(torch.int32), int(meta.max_query_len), int(meta.max_seq_len),
                                  float(self.impl.scale), out=out[:n].view(n, hq, D), req_split=split,
-                                 k_scale=self._k_scale if fp8 else None, v_scale=self._v_scale if fp8 else None)
+                                 k_scale=self._k_scale if fp8 else None, v_scale=self._v_scale if fp8 else None,
+                                 sliding_window=window, sinks=sinks)
             step_context.calls["verify"] += 1
+            return out
+
+        def _arctic_sinks(self):
+            """The layer's attention sinks as the kernel wants them (contiguous f32, one per LOCAL query head), None when
+            the layer has none, False when they cannot be mapped onto this rank's heads (the caller then uses vLLM's
+            backend).  vLLM shards the parameter over TP only; under Ulysses this rank attends with heads
+            [sp_rank * num_heads, (sp_rank + 1) * num_heads) of that shard (rank-major after the all-to-all)."""
+            raw = getattr(self.impl, "sinks", None)
+            if raw is None:
+                raw = getattr(self, "sinks", None)
+            if raw is None:
+                return None
+            cached = getattr(self, "_arctic_sinks_cache", None)
+            if cached is not None and cached[0] is raw and cached[1] == raw._version:
+                return cached[2]
+            n = raw.numel()
+            if n == self.num_heads:
+                local = raw
+            elif self.sp_size > 1 and n == self.num_heads * self.sp_size:
+                r = parallel_state._SP.rank_in_group
+                local = raw.reshape(-1)[r * self.num_heads:(r + 1) * self.num_heads]
+            else:
+                return False
+            out = local.detach().reshape(-1).to(torch.float32).contiguous()
+            self._arctic_sinks_cache = (raw, raw._version, out)
             return out
 
         def _arctic_attend(self, query, key, value, **kwargs):

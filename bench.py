@@ -60,6 +60,18 @@ def parse_args():
     ap.add_argument("--no-spec", action="store_true",
                     help="comparison run, not the headline: speculation off (no suffix cache, no draft model) — every request "
                          "decodes one token per step through the same attention + greedy sampling kernels")
+    ap.add_argument("--no-suffix", action="store_true",
+                    help="BASELINE configs[1]: the Arctic LSTM speculator alone (method \"arctic\", no suffix decoding) — the "
+                         "draft model runs in every step; a second roofline entry is reported for its kernels")
+    ap.add_argument("--proposal-indexing", default="single_advance", choices=["single_advance", "reference"],
+                    help="where a request's row ends for the proposers (vllm_plugin/runner_logic.py).  The headline runs "
+                         "\"single_advance\" (the row as the step left it: the algorithm of the reference's simulator and of "
+                         "the golden fixtures); \"reference\" is the reference plugin's literal arithmetic (sampled ids counted "
+                         "twice, model_runner.py:623-636 / :696-718).  The other mode's acceptance is measured in a few extra "
+                         "rounds after the timed region and printed beside the headline")
+    ap.add_argument("--no-replay-check", action="store_true",
+                    help="skip the one-request-at-a-time suffix replay on the golden token source (method \"suffix\", every "
+                         "draft taken; its avg_accept_toks must equal tests/golden/suffix_replay.json)")
     ap.add_argument("--kv-dtype", default="auto", choices=["auto", "fp8"], help="KV cache dtype (auto = bf16, the headline config)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--qlen-hist", action="store_true", help="diagnostic: histogram of per-request query lengths in the timed steps")
@@ -185,6 +197,92 @@ def cpu_baseline(args, src, shape, spec, run_stats):
             "cores": threads, "sample_wall_s": time.perf_counter() - t_all}
 
 
+class TimedDrafter:
+    """The draft model with a HIP event pair around every call (on the stream the call launches on: torch's current
+    stream, which is what generate_proposals passes to the library) — the second roofline entry of the line."""
+
+    def __init__(self, inner):
+        self._inner = inner
+        self.pairs = []
+
+    def __getattr__(self, name):
+        return getattr(self._inner, name)
+
+    def generate_proposals(self, *a, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = self._inner.generate_proposals(*a, **kw)
+        e1.record()
+        self.pairs.append((e0, e1, int(a[0].size(0))))
+        return out
+
+    def reset(self):
+        self.pairs = []
+
+    def summary(self, cfg, k: int):
+        """(avg us per call, calls, algorithmic weight bytes per call): k heads of gate GEMM (4Ds x H, then 4Ds x Ds, bf16)
+        + k passes over the tied LM head (fp8 when the padded batch is <= 32, else bf16), SURVEY.md 8(d) A8 / A9."""
+        if not self.pairs:
+            return None
+        us = [a.elapsed_time(b) * 1e3 for a, b, _ in self.pairs]
+        rows = max(n for _, _, n in self.pairs)
+        from arcticinference_amd.speculator import padding_size
+        m = self._inner
+        Ds, H, V = m.inner_dim, m.input_hidden_dim, m.shard_rows       # the head shard of this rank (vocab-parallel under SP)
+        head_b = 1 if (m.quantize_lm_head and padding_size(rows) <= 32) else 2      # arctic_speculator.py:726-728
+        gate = (4 * Ds * H + (k - 1) * 4 * Ds * Ds) * 2
+        head = k * V * Ds * head_b
+        return {"avg_us": float(np.mean(us)), "calls": len(us), "rows": rows, "gate_bytes": gate, "head_bytes": head,
+                "head_dtype": "fp8 e4m3" if head_b == 1 else "bf16"}
+
+
+def suffix_replay_check():
+    """The golden replay on THIS build's device suffix cache: method "suffix" (every draft taken), one request at a time,
+    on the golden token source — oracle/gen_golden.py:replay's loop (simulator.suffix_decode, simulator.py:33-114).  Its
+    avg_accept_toks must equal the compiled reference's (tests/golden/suffix_replay.json, the 64 x (4096 + 256) entry)."""
+    from arcticinference_amd.suffix_cache import SuffixCache
+    from arcticinference_amd.workload import TokenSource
+    with open(os.path.join(ROOT, "tests", "golden", "suffix_replay.json")) as f:
+        want = json.load(f)[-1]
+    c = want["config"]
+    src = TokenSource(seed=c["seed"])
+    cache = SuffixCache(c["max_depth"])
+    acc = steps = spec = 0
+    t0 = time.perf_counter()
+    for r in range(c["n_req"]):
+        prompt, gt = src.request(r, c["prompt_len"], c["gen_len"])
+        prompt, gt = [int(x) for x in prompt], [int(x) for x in gt]
+        cache.cache_prompt(r, prompt)
+        resp = []
+        while len(resp) < len(gt):
+            res = cache.speculate(r, (prompt + resp)[-c["max_depth"]:], max_spec_tokens=c["max_spec_tokens"],
+                                  max_spec_factor=c["factor"], max_spec_offset=c["offset"], min_token_prob=c["min_token_prob"])
+            a = 0
+            for tok in res.token_ids:
+                if len(resp) + a < len(gt) and gt[len(resp) + a] == tok:
+                    a += 1
+                else:
+                    break
+            new = gt[len(resp):len(resp) + a]
+            resp.extend(new)
+            if len(resp) < len(gt):
+                new = new + [gt[len(resp)]]
+                resp.append(gt[len(resp)])
+            cache.update_response(r, new)
+            steps += 1
+            acc += a
+            spec += len(res.token_ids)
+        cache.evict_prompt(r)
+    got = acc / steps
+    return {"avg_accept_toks": got, "sum_accept": acc, "steps": steps, "sum_spec": spec,
+            "golden_avg_accept_toks": want["avg_accept_toks"], "golden_sum_accept": want["sum_accept"],
+            "golden_steps": want["steps"],
+            "equal_to_reference": bool(acc == want["sum_accept"] and steps == want["steps"] and spec == want["sum_spec"]),
+            "wall_s": time.perf_counter() - t0,
+            "what": "method \"suffix\" (every draft taken), one request at a time, golden token source, run on this build's "
+                    "device suffix cache just now; golden = the compiled reference's run (tests/golden/suffix_replay.json)"}
+
+
 def spawn_ranks(args) -> int:
     """`bench.py --gpus N` without a launcher: start N ranks as a CHILD process tree (never an exec: this process has
     not touched the GPU, and must not before the children exist) and hand back their exit code."""
@@ -238,7 +336,8 @@ def main():
     if args.long_splits:
         N.check(N.lib().aic_debug_attn_long_splits(args.long_splits))
     shape = ModelShape(num_layers=args.layers)
-    spec = SpecConfig(draft_model_per_request=args.draft_model_per_request)
+    spec = SpecConfig(draft_model_per_request=args.draft_model_per_request, proposal_indexing=args.proposal_indexing,
+                      enable_suffix_decoding=not args.no_suffix)
     if args.no_spec:
         spec = SpecConfig(method="none", enable_suffix_decoding=False)
         args.no_lstm = True
@@ -268,6 +367,8 @@ def main():
         drafter.load_weights(lstm_ckpt.items())
         if rank != 0 or world > 1 or args.no_cpu_baseline:
             lstm_ckpt = None            # rank 0 of a single-GPU run keeps the host copy for the cpu_baseline leg
+        draft_cfg = cfg
+        drafter = TimedDrafter(drafter)
 
     eng = HotPathEngine(shape, spec, B, max_model_len, drafter, device=dev, ulysses=ulysses, seed=args.seed,
                         kv_cache_dtype=args.kv_dtype)
@@ -358,6 +459,8 @@ def main():
         eng.qlen_hist = np.zeros(40, dtype=np.int64)
     if ulysses is not None:
         ulysses.steps_sp = ulysses.steps_shift = 0
+    if drafter is not None:
+        drafter.reset()
     attn_bytes[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -380,6 +483,37 @@ def main():
     replaced_total = replaced[0]
     steps_shift = ulysses.steps_shift if ulysses is not None else 0
     steps_sp = ulysses.steps_sp if ulysses is not None else 0
+    draft_timing = drafter.summary(draft_cfg, spec.num_speculative_tokens) if drafter is not None else None
+
+    # the OTHER reading of the proposal indexing, a few rounds on the same engine outside `value` (every rank runs them:
+    # the control flow is replicated): its acceptance and step time go into the line beside the headline mode's
+    other_mode = None
+    if eng.suffix_cache is not None and not args.no_spec:
+        from arcticinference_amd.vllm_plugin.runner_logic import INDEXING_MODES
+        other = [m for m in INDEXING_MODES if m != eng._indexing][0]
+        headline_mode, eng._indexing = eng._indexing, other
+        k3 = max(8, min(24, args.steps))
+        for _ in range(4):                      # the drafts in flight were proposed under the headline mode: let them drain
+            run_step()
+        barrier()
+        gen_tokens[0] = 0
+        eng.stats = type(eng.stats)()
+        t1 = time.perf_counter()
+        for _ in range(k3):
+            run_step()
+        barrier()
+        dt = time.perf_counter() - t1
+        so = eng.stats
+        other_mode = {"proposal_indexing": other, "rounds": k3, "tokens_per_s": gen_tokens[0] / dt, "ms_per_step": dt / k3 * 1e3,
+                      "tokens_per_request_step": so.emitted / max(k3 * B, 1),
+                      "accepted_per_request_step": so.accepted / max(k3 * B, 1),
+                      "mean_accepted_draft_len": so.accepted / max(so.num_drafts, 1),
+                      "suffix_share_of_request_steps": so.suffix_used / max(k3 * B, 1),
+                      "steps_with_draft_model": so.draft_model_steps, "lane_steps": so.steps}
+        eng._indexing = headline_mode
+        for _ in range(2):
+            run_step()
+        barrier()
 
     # N > 1 with shift parallelism: the decode-size steps above ran in shift (TP) mode.  A few extra steps, outside
     # `value`, with shift off put the Ulysses all-to-all path (2 RCCL all_to_all_single per layer) on the record too.
@@ -433,6 +567,12 @@ def main():
                     break
                 except Exception:
                     traffic = None
+        replay_check = None
+        if world == 1 and not args.no_replay_check and not args.no_spec:
+            try:
+                replay_check = suffix_replay_check()
+            except Exception as e:                      # noqa: BLE001 - reported, not swallowed
+                replay_check = {"error": "%s: %s" % (type(e).__name__, e)}
         golden_accept = None
         try:
             with open(os.path.join(ROOT, "tests", "golden", "suffix_replay.json")) as f:
@@ -458,10 +598,14 @@ def main():
             "config": {
                 "workload": ("Llama-3.1-8B shapes (L=%d, Hq=32, Hkv=8, D=128, V=128256), %sB=%d live requests, "
                              "%d-token prompts, %d generated tokens each, greedy, KV cache %s; hot path only (verify "
-                             "attention, acceptance, suffix + LSTM proposal, KV write); target dense layers synthetic"
+                             "attention, acceptance, suffix + LSTM proposal, KV write); target dense layers synthetic — NOT an "
+                             "end-to-end serving number; the north-star comparison against vanilla vLLM-ROCm (>= 2x) could "
+                             "not be run: vLLM is installed neither in the build container nor on the GPU box"
                              % (shape.num_layers,
                                 "SPECULATION OFF (comparison run: one token per request-step), " if args.no_spec else
-                                "arctic LSTM speculator k=3 (Ds=4096, fp8 head when padded batch <= 32) + suffix decoding, ",
+                                ("arctic LSTM speculator k=3 (Ds=4096, fp8 head when padded batch <= 32), NO suffix decoding "
+                                 "(BASELINE configs[1]: the draft model runs every step), " if args.no_suffix else
+                                 "arctic LSTM speculator k=3 (Ds=4096, fp8 head when padded batch <= 32) + suffix decoding, "),
                                 B, PL, GL, "bf16" if args.kv_dtype == "auto" else "fp8 e4m3")),
                 "global_batch": B, "prompt_len": PL, "gen_len": GL,
                 "lanes": n_lanes,
@@ -478,7 +622,19 @@ def main():
             "steps_in_shift_mode": steps_shift, "steps_in_sp_mode": steps_sp,
             "ulysses_all_to_all_path_ms_per_step": a2a_ms,
             "ulysses_all_to_all_path_error": a2a_error,
+            "proposal_indexing": eng._indexing,
+            "proposal_indexing_note": ("headline mode \"single_advance\": a request's row is taken as the step left it (the "
+                                       "reference simulator's / golden fixtures' algorithm); the reference PLUGIN counts the "
+                                       "sampled ids twice (model_runner.py:623-636, :696-718) — that mode is "
+                                       "\"other_indexing_mode\" below and the library's default"
+                                       if eng._indexing == "single_advance" else
+                                       "headline mode \"reference\": the reference plugin's literal arithmetic"),
+            "other_indexing_mode": other_mode,
+            # per DRAFT (the counters of stats.py:29-33) and per REQUEST-STEP (the simulator's avg_accept_toks,
+            # simulator.py:224-229: accepted tokens / steps) — only the latter compares with reference_suffix_replay
             "mean_accepted_draft_len": st.accepted / max(st.num_drafts, 1),
+            "accepted_per_request_step": st.accepted / max(args.steps * B, 1),
+            "suffix_replay_check": replay_check,
             "reference_suffix_replay": golden_accept,
             "requests_replaced_in_timed_region": replaced_total,
             "draft_model_policy": ("per request (extension)" if spec.draft_model_per_request else
@@ -502,6 +658,18 @@ def main():
                                     ", in every 5th engine step (those go out kernel by kernel; the other steps' layers are "
                                     "HIP graph launches, which carry no events)")},
         }
+        if draft_timing is not None:
+            db = draft_timing["gate_bytes"] + draft_timing["head_bytes"]
+            da = db / (draft_timing["avg_us"] * 1e-6) / 1e9
+            line["roofline_draft_model"] = {
+                "bound": "hbm", "kernel": "skinny_gemm_kernel (gate + LM head) + lstm_cell kernels, one k=%d draft call"
+                                          % spec.num_speculative_tokens,
+                "achieved": da, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": da / HBM_PEAK_GBS, "traffic": None,
+                "avg_call_us": draft_timing["avg_us"], "calls_timed": draft_timing["calls"], "rows": draft_timing["rows"],
+                "algorithmic_bytes_per_call": db, "gate_bytes": draft_timing["gate_bytes"],
+                "head_bytes": draft_timing["head_bytes"], "head_dtype": draft_timing["head_dtype"],
+                "note": "weights read once per head (SURVEY 8(d) A8 + A9); every call in the timed region bracketed by a "
+                        "HIP event pair on its launch stream"}
         if not args.no_cpu_baseline and world == 1:
             toks_per_req_step = st.emitted / max(args.steps * B, 1)
             cb = cpu_baseline(args, src, shape, spec, {"steps": st.steps, "draft_model_steps": st.draft_model_steps,
@@ -523,6 +691,10 @@ def main():
             line["cpu_baseline"] = {
                 "value": B * toks_per_req_step / cb["step_seconds"], "unit": "tokens/s",
                 "cores": cb["cores"], "kind": "port",
+                "kind_by_part": {"suffix_update_and_speculate + prompt_tree_build":
+                                 "reference (oracle/_ref)" if cb["suffix_tree"].startswith("reference") else "port",
+                                 "attention_32_layers": "port (torch-CPU SDPA: the reference has no CPU attention of its own)",
+                                 "rejection": "port", "draft_model": "port (oracle.spec_oracle, the reference's op sequence)"},
                 "sample": "one engine step of the same B=%d workload on the host cores: torch-CPU SDPA over all %d requests "
                           "(bf16, GQA folded into the query rows, ctx %d) on 2 of %d layers scaled; arg-max acceptance on "
                           "[%d, V]; suffix proposer = %s under the SuffixCache policy restatement, %d prompt trees + 8 steps "

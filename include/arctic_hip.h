@@ -357,6 +357,21 @@ int aic_verify_attention_ex(const void* q, int64_t q_stride, const void* k_cache
                             void* out, int64_t out_stride, void* workspace, size_t workspace_bytes,
                             int max_seq_len, const int32_t* short_reqs, int n_short, const int32_t* long_reqs,
                             int n_long, void* stream);
+/* The same with the two per-layer features of gpt-oss-class models (BASELINE configs[4]; on the reference path they are
+ * arguments of vLLM's Attention layer, which `self._orig_forward` reaches, ulysses.py:510):
+ *   sliding_window W > 0: query position p attends keys p - W + 1 .. p only (0: the whole context) — a request then
+ *       streams its last W + q_len tokens instead of its context;
+ *   sinks: device f32 [num_q_heads] (NULL: none) — one extra logit per head that takes part in the soft-max
+ *       normalisation and carries no value (not multiplied by sm_scale).
+ * aic_verify_attention_ex(...) == aic_verify_attention_win(..., 0, NULL, stream). */
+int aic_verify_attention_win(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
+                             int64_t block_stride, int kv_dtype, const float* k_scale, const float* v_scale,
+                             const int32_t* block_table, int max_blocks_per_seq, const int32_t* seq_lens,
+                             const int32_t* query_start_loc, int batch, int num_tokens, int max_q_len,
+                             int num_q_heads, int num_kv_heads, int head_size, int block_size, float sm_scale,
+                             void* out, int64_t out_stride, void* workspace, size_t workspace_bytes,
+                             int max_seq_len, const int32_t* short_reqs, int n_short, const int32_t* long_reqs,
+                             int n_long, int sliding_window, const float* sinks, void* stream);
 /* aic_verify_attention_ex for `n_layers` layers of one engine step in one call: k_caches / v_caches are HOST arrays of
  * device pointers (one cache pair per layer, same shape / dtype / strides), q and out advance by *_layer_stride elements
  * per layer (0: shared).  For drivers that own the whole step (arcticinference_amd/engine.py); inside vLLM attention is

@@ -229,8 +229,12 @@ def rejection_random(target_logits: torch.Tensor, draft_token_ids: Sequence[int]
 # ----------------------------------------------------------------------------------------------
 def verify_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_table: torch.Tensor,
                      seq_lens: Sequence[int], query_start_loc: Sequence[int], sm_scale: float, k_scale: float = 1.0,
-                     v_scale: float = 1.0) -> torch.Tensor:
-    """q [T,Hq,D]; caches [num_blocks, block_size, Hkv, D]; returns fp32 [T,Hq,D]."""
+                     v_scale: float = 1.0, sliding_window: int = 0, sinks: torch.Tensor = None) -> torch.Tensor:
+    """q [T,Hq,D]; caches [num_blocks, block_size, Hkv, D]; returns fp32 [T,Hq,D].
+    gpt-oss layers (BASELINE configs[4]; semantics of vLLM's attention backends, recalled — parity unpinned):
+    `sliding_window` W > 0: query position p sees keys p - W + 1 .. p only (W keys, itself included);
+    `sinks` f32 [Hq]: one extra logit per head that takes part in the soft-max normalisation and carries no value
+    (softmax over [scores, sink], the sink column dropped): it is NOT multiplied by sm_scale."""
     T, Hq, D = q.shape
     _, bs, Hkv, _ = k_cache.shape
     G = Hq // Hkv
@@ -250,8 +254,14 @@ def verify_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
         s = torch.einsum("qhd,khd->hqk", Q, Kh) * sm_scale
         pos = torch.arange(qlen).unsqueeze(1) + (ctx - qlen)
         mask = torch.arange(ctx).unsqueeze(0) <= pos             # [qlen, ctx]
+        if sliding_window and sliding_window > 0:
+            mask = mask & (torch.arange(ctx).unsqueeze(0) > pos - sliding_window)
         s = s.masked_fill(~mask.unsqueeze(0), float("-inf"))
-        p = torch.softmax(s, dim=-1)
+        if sinks is not None:
+            col = sinks.float().view(Hq, 1, 1).expand(Hq, qlen, 1)
+            p = torch.softmax(torch.cat([s, col], dim=-1), dim=-1)[..., :ctx]
+        else:
+            p = torch.softmax(s, dim=-1)
         out[q0:q1] = torch.einsum("hqk,khd->qhd", p, Vh)
     return out
 

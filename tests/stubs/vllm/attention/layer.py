@@ -27,10 +27,11 @@ class AttentionMetadata:
 
 
 class _Impl:
-    def __init__(self, scale):
+    def __init__(self, scale, sinks=None):
         self.scale = scale
         self.alibi_slopes = None
         self.logits_soft_cap = None
+        self.sinks = sinks          # [num_heads] extra soft-max logits (gpt-oss), or None
 
 
 class Attention(torch.nn.Module):
@@ -42,7 +43,7 @@ class Attention(torch.nn.Module):
         super().__init__()
         self.num_heads, self.head_size = num_heads, head_size
         self.num_kv_heads = num_kv_heads if num_kv_heads is not None else num_heads
-        self.impl = _Impl(scale)
+        self.impl = _Impl(scale, extra.get("sinks"))
         self.layer_name = prefix
         self.sliding_window = per_layer_sliding_window
         self.kv_cache = [torch.tensor([])]
@@ -89,6 +90,13 @@ class Attention(torch.nn.Module):
             s = torch.einsum("qhd,khd->hqk", q[q0:q1], K) * self.impl.scale
             pos = torch.arange(ql, device=query.device).unsqueeze(1) + (ctx_len - ql)
             mask = torch.arange(ctx_len, device=query.device).unsqueeze(0) <= pos
+            if self.sliding_window:                 # the last `sliding_window` keys, the query's own included
+                mask = mask & (torch.arange(ctx_len, device=query.device).unsqueeze(0) > pos - self.sliding_window)
             s = s.masked_fill(~mask.unsqueeze(0), float("-inf"))
-            out[q0:q1] = torch.einsum("hqk,khd->qhd", torch.softmax(s, dim=-1), V).reshape(ql, Hq * D).to(out.dtype)
+            if self.impl.sinks is not None:         # one extra logit per head in the normalisation, no value
+                col = self.impl.sinks.float().to(s.device).view(Hq, 1, 1).expand(Hq, ql, 1)
+                p = torch.softmax(torch.cat([s, col], dim=-1), dim=-1)[..., :ctx_len]
+            else:
+                p = torch.softmax(s, dim=-1)
+            out[q0:q1] = torch.einsum("hqk,khd->qhd", p, V).reshape(ql, Hq * D).to(out.dtype)
         return out

@@ -94,6 +94,8 @@ class HfConfig:
     head_dim: int = 64
     vocab_size: int = 2000
     seed: int = 0
+    sliding_window: Any = None        # gpt-oss-like: every other layer attends over the last `sliding_window` tokens
+    attention_sinks: bool = False     # ... and every layer has one learned sink logit per head
 
 
 @dataclass

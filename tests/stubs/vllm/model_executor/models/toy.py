@@ -29,7 +29,14 @@ class ToyLayer(torch.nn.Module):
         self.wv = sl(wv, self.hkv, kv_rank).to(dtype).to(device)
         self.wo = wo.view(H, hq, D)[:, r * self.hq:(r + 1) * self.hq].reshape(H, self.hq * D).to(dtype).to(device)
         self.tp = tp
-        self.attn = Attention(self.hq, D, D ** -0.5, num_kv_heads=self.hkv, prefix=f"{prefix}layers.{index}.attn")
+        # gpt-oss-like options of the config: a sliding window on every other layer, learned sinks on all of them
+        window = getattr(hf, "sliding_window", None) if index % 2 == 1 else None
+        sinks = None
+        if getattr(hf, "attention_sinks", False):
+            all_sinks = torch.randn(hq, generator=gen) * 2
+            sinks = all_sinks[r * self.hq:(r + 1) * self.hq].to(dtype).to(device)     # sharded over TP like vLLM's parameter
+        self.attn = Attention(self.hq, D, D ** -0.5, num_kv_heads=self.hkv, prefix=f"{prefix}layers.{index}.attn",
+                              per_layer_sliding_window=window, **({"sinks": sinks} if sinks is not None else {}))
         self.attn._k_scale = self.attn._k_scale.to(device)      # vLLM keeps the cache scales on the layer's device
         self.attn._v_scale = self.attn._v_scale.to(device)
 

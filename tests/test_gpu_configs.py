@@ -210,7 +210,7 @@ def test_opt125m_suffix_only_engine_loop():
     from oracle.suffix_oracle import OracleSuffixCache
     shape = ModelShape(num_layers=12, num_q_heads=12, num_kv_heads=12, head_size=64, hidden_size=768, vocab_size=50272,
                        block_size=16)
-    spec = SpecConfig(method="suffix", enable_suffix_decoding=True)
+    spec = SpecConfig(method="suffix", enable_suffix_decoding=True, proposal_indexing="single_advance")
     B, PL, limit = 6, 160, 520
     eng = HotPathEngine(shape, spec, B, limit, None, device=DEV, seed=0)
     src = TokenSource(vocab_size=50272, seed=5, n_motifs=4, motif_min=8, motif_max=24, p_motif=0.8)

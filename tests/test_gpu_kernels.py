@@ -315,6 +315,74 @@ def test_verify_attention_head_size_64(cfg):
         assert torch.allclose(got.float().cpu(), want, atol=1e-3, rtol=2 ** -8), (extra, (got.float().cpu() - want).abs().max())
 
 
+@pytest.mark.parametrize("cfg", [
+    # gpt-oss-120b heads (Hq 64, Hkv 8, D 64) and their SP = 8 slice (Hq 8, Hkv 1): window 128 + sinks, k = 3 and suffix drafts
+    dict(B=4, Hq=64, Hkv=8, D=64, q_lens=[4, 1, 3, 4], ctxs=[300, 17, 1025, 4100], bs=16, window=128, sinks=True),
+    dict(B=4, Hq=8, Hkv=1, D=64, q_lens=[4, 33, 9, 2], ctxs=[1500, 2600, 130, 64], bs=16, window=128, sinks=True),
+    dict(B=4, Hq=8, Hkv=1, D=64, q_lens=[4, 33, 9, 2], ctxs=[1500, 2600, 130, 64], bs=16, window=0, sinks=True),   # full-attention layer
+    dict(B=3, Hq=64, Hkv=8, D=64, q_lens=[33, 20, 5], ctxs=[700, 95, 160], bs=32, window=128, sinks=False),
+    # the same features at head size 128 (short body, long body, one-grid pair launch, token-split waves, fp8 cache)
+    dict(B=5, Hq=32, Hkv=8, D=128, q_lens=[4, 33, 2, 17, 4], ctxs=[900, 1300, 64, 2100, 33], bs=16, window=128, sinks=True),
+    dict(B=4, Hq=4, Hkv=1, D=128, q_lens=[4, 4, 2, 4], ctxs=[4100, 99, 5, 4], bs=16, window=64, sinks=True),
+    dict(B=4, Hq=32, Hkv=8, D=128, q_lens=[4, 33, 2, 9], ctxs=[900, 1300, 64, 700], bs=32, window=200, sinks=True, fp8=True),
+    dict(B=3, Hq=16, Hkv=2, D=128, q_lens=[1, 1, 1], ctxs=[31, 32, 33], bs=16, window=32, sinks=True),    # window == a tile, contexts around it
+    dict(B=2, Hq=8, Hkv=2, D=128, q_lens=[5, 2], ctxs=[5, 2], bs=16, window=3, sinks=True),              # window shorter than the draft; ctx == q_len
+    dict(B=2, Hq=8, Hkv=8, D=128, q_lens=[3, 1], ctxs=[4000, 2500], bs=16, window=0, sinks=True),         # sinks over many splits (counted once)
+])
+def test_verify_attention_sliding_window_and_sinks(cfg):
+    """gpt-oss layers (BASELINE configs[4]): the sliding-window bound and the per-head sink term, against the fp32 oracle
+    (parity unpinned against vLLM's backends: semantics recalled, oracle cross-checked in tests/test_oracle_attention.py).
+    Both call forms (with and without the host partition), forced split counts included: a sink must be counted once
+    however a row's range is split, and a window must shorten the range without moving its upper edge."""
+    from arcticinference_amd import _native as N
+    D = cfg["D"]
+    q, kc, vc, bt, qsl = _attn_case(cfg["B"], cfg["Hq"], cfg["Hkv"], D, cfg["q_lens"], cfg["ctxs"], cfg["bs"], seed=31)
+    g = torch.Generator().manual_seed(77)
+    sinks = (torch.randn(cfg["Hq"], generator=g) * 3).float() if cfg["sinks"] else None
+    ks = vs = 1.0
+    kw = {}
+    if cfg.get("fp8"):
+        ks, vs = 0.043, 0.021
+        kc, vc = O.fp8_sat(kc.float() / ks, "e4m3"), O.fp8_sat(vc.float() / vs, "e4m3")
+        kw = dict(k_scale=torch.tensor([ks], device=DEV), v_scale=torch.tensor([vs], device=DEV))
+    scale = D ** -0.5
+    want = O.verify_attention(q, kc, vc, bt, cfg["ctxs"], qsl, scale, ks, vs, sliding_window=cfg["window"], sinks=sinks)
+    plain = O.verify_attention(q, kc, vc, bt, cfg["ctxs"], qsl, scale, ks, vs)
+    assert not torch.allclose(want, plain, atol=1e-2), "the case does not exercise the feature"
+    args = (q.to(DEV), kc.to(DEV), vc.to(DEV), bt.to(DEV), torch.tensor(cfg["ctxs"], dtype=torch.int32, device=DEV),
+            torch.tensor(qsl, device=DEV), max(cfg["q_lens"]), max(cfg["ctxs"]), scale)
+    dsinks = None if sinks is None else sinks.to(DEV)
+    try:
+        for splits in (0, 1, 3):
+            N.lib().aic_debug_attn_layout(0, splits)
+            for lens in (cfg["q_lens"], None):
+                out = torch.full((sum(cfg["q_lens"]), cfg["Hq"], D), float("nan"), dtype=torch.bfloat16, device=DEV)
+                got = _ops().verify_attention(*args, out=out, q_lens_host=lens, sliding_window=cfg["window"], sinks=dsinks,
+                                              **kw).float().cpu()
+                assert torch.allclose(got, want, atol=1e-3, rtol=2 ** -8), (splits, lens is None, float((got - want).abs().max()))
+    finally:
+        N.lib().aic_debug_attn_layout(0, 0)
+
+
+def test_verify_attention_window_reads_only_the_window():
+    """A windowed layer must not depend on anything before the window: poisoning every cache page that lies wholly below
+    (ctx - q_len - window + 1) with NaN leaves the result unchanged (the range really is shortened, not just masked)."""
+    D, Hq, Hkv, W = 64, 64, 8, 128
+    q_lens, ctxs = [4, 1, 7], [3000, 1500, 700]
+    q, kc, vc, bt, qsl = _attn_case(3, Hq, Hkv, D, q_lens, ctxs, 16, seed=5)
+    args = lambda k, v: (q.to(DEV), k.to(DEV), v.to(DEV), bt.to(DEV), torch.tensor(ctxs, dtype=torch.int32, device=DEV),
+                         torch.tensor(qsl, device=DEV), max(q_lens), max(ctxs), D ** -0.5)
+    clean = _ops().verify_attention(*args(kc, vc), q_lens_host=q_lens, sliding_window=W)
+    kp, vp = kc.clone(), vc.clone()
+    for i, (ql, ctx) in enumerate(zip(q_lens, ctxs)):
+        first_needed = ((ctx - ql - W + 1) // 32) * 32          # the kernel starts at a 32-token tile boundary
+        for blk in range(first_needed // 16):
+            kp[int(bt[i, blk])] = float("nan")
+            vp[int(bt[i, blk])] = float("nan")
+    poisoned = _ops().verify_attention(*args(kp, vp), q_lens_host=q_lens, sliding_window=W)
+    assert torch.equal(clean, poisoned) and not torch.isnan(clean.float()).any()
+
+
 @pytest.mark.parametrize("seed", list(range(16)))
 def test_verify_attention_random_shapes(seed):
     """Seeded random batches over the head geometries the path serves (group size 1 / 2 / 4 / 8, 1 / 2 / 4 / 8 kv heads per

@@ -16,7 +16,7 @@ from arcticinference_amd.workload import TokenSource
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 n_lanes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 B, PL, GL = 64, 4096, 256
-shape, spec = ModelShape(), SpecConfig()
+shape, spec = ModelShape(), SpecConfig(proposal_indexing="single_advance")
 src = TokenSource(seed=0)
 eng = HotPathEngine(shape, spec, B, PL + GL + 64, None, device="cuda", seed=0)
 pool = [src.stream(PL + GL + 128, r) for r in range(B + 40)]
