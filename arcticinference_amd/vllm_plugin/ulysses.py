@@ -230,10 +230,12 @@ def build_ulysses_patches():
             another cache layout, no metadata): the caller then uses vLLM's backend."""
             if not query.is_cuda:
                 return None
-            if torch.cuda.is_current_stream_capturing():
-                # full-graph capture would freeze this step's host-side geometry (split counts, max_seq_len) into the
-                # graph; vLLM's default piecewise graphs run attention outside the captured pieces and never get here
-                return None
+            # Full-graph capture (vLLM's full_cuda_graph; its default piecewise graphs cut at this op and never get here):
+            # the launch is recorded with the geometry of the capture-time metadata — request count, token count,
+            # max_query_len and a max_seq_len that bounds every later replay — and reads the per-request lengths, the block
+            # table and the slots from the persistent device buffers vLLM refreshes before each replay.  The host-side
+            # request partition of the step (step_context) would freeze ONE step's lists into the graph: not used here.
+            capturing = torch.cuda.is_current_stream_capturing()
             ctx = get_forward_context()
             meta = ctx.attn_metadata
             if isinstance(meta, dict):
@@ -271,10 +273,12 @@ def build_ulysses_patches():
             q = query[:n].unflatten(-1, (hq, D)) if query.dim() == 2 else query[:n]
             out = torch.empty((query.shape[0], hq * D), dtype=query.dtype, device=query.device)
             batch = meta.seq_lens.numel()
-            split = step_context.request_split(hq // self.num_kv_heads, query.device)
-            ql = step_context.q_lens()
-            if ql is not None and len(ql) != batch:
-                split = None                                   # the published step does not describe this call
+            split = None
+            if not capturing:
+                split = step_context.request_split(hq // self.num_kv_heads, query.device)
+                ql = step_context.q_lens()
+                if ql is not None and len(ql) != batch:
+                    split = None                               # the published step does not describe this call
             ops.verify_attention(q, k_cache, v_cache, meta.block_table, meta.seq_lens.to(torch.int32),
                                  meta.query_start_loc.to(torch.int32), int(meta.max_query_len), int(meta.max_seq_len),
                                  float(self.impl.scale), out=out[:n].view(n, hq, D), req_split=split,

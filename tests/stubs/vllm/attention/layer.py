@@ -65,10 +65,10 @@ class Attention(torch.nn.Module):
             meta = meta[self.layer_name]
         kv = self.kv_cache[ctx.virtual_engine]
         Hq, Hkv, D = self.num_heads, self.num_kv_heads, self.head_size
-        n = meta.num_actual_tokens
         out = torch.zeros(query.shape[0], Hq * D, dtype=query.dtype, device=query.device)
-        if kv.numel() == 0:            # profile run: no cache bound yet
+        if meta is None or kv.numel() == 0:     # profile / warm-up run without metadata, or no cache bound yet
             return out
+        n = meta.num_actual_tokens
         bs = kv.shape[2]
         kc, vc = kv[0].view(-1, Hkv, D), kv[1].view(-1, Hkv, D)
         slots = meta.slot_mapping[:n]

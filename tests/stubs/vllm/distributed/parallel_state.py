@@ -15,19 +15,35 @@ _PP = None
 _DP = None
 _EP = None
 _TP_STATE_PATCHED = False
+# (stand-in only) a one-process REHEARSAL of an N-rank layout: set to N before the groups are built and every
+# GroupCoordinator becomes rank 0 of a group whose other members do not exist (no torch.distributed groups are made);
+# `device_group` is then a VirtualGroup and the test supplies the collectives (mirror ranks: every peer holds what this
+# rank holds).  Lets a single GPU process walk the SP / shift code paths with collectives that a HIP graph can capture.
+VIRTUAL_WORLD = None
+
+
+class VirtualGroup:
+    def __init__(self, size: int):
+        self.size = size
+
+    def __repr__(self):
+        return f"VirtualGroup({self.size})"
 
 
 class GroupCoordinator:
     def __init__(self, group_ranks: List[List[int]], local_rank: int, backend: Optional[str], group_name: str,
                  use_message_queue_broadcaster: bool = False):
         self.unique_name = group_name
-        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.rank = dist.get_rank() if dist.is_initialized() and not VIRTUAL_WORLD else 0
         self.local_rank = local_rank
         self.device_group = None
         self.ranks = None
         self.all_group_ranks = group_ranks
         for ranks in group_ranks:                      # every rank creates every group, in the same order
-            g = dist.new_group(ranks, backend=backend) if dist.is_initialized() and len(ranks) > 1 else None
+            if VIRTUAL_WORLD:
+                g = VirtualGroup(len(ranks)) if len(ranks) > 1 else None
+            else:
+                g = dist.new_group(ranks, backend=backend) if dist.is_initialized() and len(ranks) > 1 else None
             if self.rank in ranks:
                 self.ranks, self.device_group = ranks, g
         assert self.ranks is not None, (group_name, self.rank, group_ranks)
@@ -46,6 +62,8 @@ class GroupCoordinator:
         return self.rank_in_group == self.world_size - 1
 
     def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world_size > 1 and isinstance(self.device_group, VirtualGroup):
+            return t.mul_(self.world_size)             # mirror ranks: the sum of world_size equal shares
         if self.world_size > 1:
             if t.is_cuda and dist.get_backend(self.device_group) == "gloo":     # ranks sharing one GPU in tests
                 host = t.cpu()
@@ -81,7 +99,7 @@ def init_model_parallel_group(group_ranks, local_rank, backend, use_message_queu
 
 def init_world_group(local_rank: int = 0):
     global _WORLD
-    n = dist.get_world_size() if dist.is_initialized() else 1
+    n = VIRTUAL_WORLD or (dist.get_world_size() if dist.is_initialized() else 1)
     _WORLD = GroupCoordinator([list(range(n))], local_rank, dist.get_backend() if dist.is_initialized() else None, "world")
     return _WORLD
 
@@ -104,7 +122,7 @@ def get_pp_group():
 def initialize_model_parallel(tensor_model_parallel_size: int = 1, pipeline_model_parallel_size: int = 1,
                               backend: Optional[str] = None) -> None:
     global _TP, _PP, _DP, _EP
-    n = dist.get_world_size() if dist.is_initialized() else 1
+    n = VIRTUAL_WORLD or (dist.get_world_size() if dist.is_initialized() else 1)
     tp, pp = tensor_model_parallel_size, pipeline_model_parallel_size
     lr = get_world_group().local_rank
     _TP = init_model_parallel_group([list(range(i, i + tp)) for i in range(0, n, tp)], lr, backend, True, "tp")
@@ -115,7 +133,7 @@ def initialize_model_parallel(tensor_model_parallel_size: int = 1, pipeline_mode
 
 @contextmanager
 def graph_capture(device):
-    context = GraphCaptureContext(None)
+    context = GraphCaptureContext(torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None)
     with _TP.graph_capture(context), _PP.graph_capture(context):
         yield context
 

@@ -16,4 +16,5 @@ def get_model(*, vllm_config):
     finally:
         set_current_vllm_config(prev)
     loaded.append((arch, get_tp_group().world_size))
-    return model
+    from vllm.compilation import cuda_graphs
+    return cuda_graphs.install(model, vllm_config)

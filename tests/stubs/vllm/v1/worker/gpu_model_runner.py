@@ -154,6 +154,15 @@ class GPUModelRunner:
         self.sampler = Sampler()
         self.kv_caches: List[torch.Tensor] = []
         self.dummy_runs: List[tuple] = []      # (num_tokens, which model, tp world size, is_profile) — tests read it
+        self.execute_dummy_runs = False        # tests on the GPU set it: _dummy_run then really runs the model
+        # full-graph mode: everything attention reads lives in persistent buffers (a captured graph holds their addresses)
+        self._md = None
+        if self.full_cuda_graph:
+            dev = self.device
+            self._md = {"qsl": torch.zeros(self.max_num_reqs + 1, dtype=torch.int32, device=dev),
+                        "seq": torch.zeros(self.max_num_reqs, dtype=torch.int32, device=dev),
+                        "bt": torch.zeros(self.max_num_reqs, max_blocks, dtype=torch.int32, device=dev),
+                        "slots": torch.full((self.max_num_tokens + 64,), -1, dtype=torch.int64, device=dev)}
         if self.speculative_config is not None:
             # vLLM's constructor knows its own methods only (the plugin hides "arctic" / "suffix" from it)
             if self.speculative_config.method != "ngram":
@@ -211,11 +220,14 @@ class GPUModelRunner:
         dev = self.device
         self.input_ids[:T] = torch.from_numpy(toks.astype(np.int64)).to(dev)
         self.positions[:T] = torch.from_numpy(pos.astype(np.int64)).to(dev)
-        meta = AttentionMetadata(num_actual_tokens=T, max_query_len=int(n_sched.max()),
-                                 query_start_loc=torch.from_numpy(qsl).to(dev), max_seq_len=int(seq_lens.max()),
-                                 seq_lens=torch.from_numpy(seq_lens).to(dev),
-                                 block_table=torch.from_numpy(ib.block_table[:B].copy()).to(dev),
-                                 slot_mapping=torch.from_numpy(slots).to(dev), query_start_loc_cpu=qsl, seq_lens_cpu=seq_lens)
+        if self._md is None:
+            meta = AttentionMetadata(num_actual_tokens=T, max_query_len=int(n_sched.max()),
+                                     query_start_loc=torch.from_numpy(qsl).to(dev), max_seq_len=int(seq_lens.max()),
+                                     seq_lens=torch.from_numpy(seq_lens).to(dev),
+                                     block_table=torch.from_numpy(ib.block_table[:B].copy()).to(dev),
+                                     slot_mapping=torch.from_numpy(slots).to(dev), query_start_loc_cpu=qsl, seq_lens_cpu=seq_lens)
+        else:
+            meta = self._fill_persistent_metadata(qsl, seq_lens, ib.block_table[:B], slots, int(n_sched.max()))
         attn_metadata = {name: meta for name in self.compilation_config.static_forward_context}
         n_draft = np.array([len(scheduler_output.scheduled_spec_decode_tokens.get(r, ())) for r in ib.req_ids], dtype=np.int32)
         if n_draft.sum() == 0:
@@ -239,7 +251,25 @@ class GPUModelRunner:
                                       bonus_logits_indices=torch.from_numpy((cu_samp - 1).astype(np.int32)).to(dev),
                                       logits_indices=torch.from_numpy(li.astype(np.int32)).to(dev))
             logits_indices = spec.logits_indices.long()
-        return attn_metadata, False, logits_indices, spec, n_sched
+        # vLLM 0.9.2's FlashAttention builder: a batch can run inside a full graph iff it is decode-only
+        attention_cuda_graphs = bool(self.full_cuda_graph and int(n_sched.max()) == 1)
+        return attn_metadata, attention_cuda_graphs, logits_indices, spec, n_sched
+
+    def _fill_persistent_metadata(self, qsl, seq_lens, block_table, slots, max_query_len, max_seq_len=None):
+        """Writes a batch into the persistent buffers and neutralises what lies behind it (requests without tokens, slot -1)
+        — a graph captured for more requests / tokens than this step has reads those entries too."""
+        md, B, T = self._md, len(seq_lens), len(slots)
+        md["qsl"][:B + 1].copy_(torch.from_numpy(np.ascontiguousarray(qsl)), non_blocking=True)
+        md["qsl"][B + 1:].fill_(int(qsl[-1]))
+        md["seq"][:B].copy_(torch.from_numpy(np.ascontiguousarray(seq_lens)))
+        md["seq"][B:].fill_(0)
+        md["bt"][:B].copy_(torch.from_numpy(np.ascontiguousarray(block_table)))
+        md["slots"][:T].copy_(torch.from_numpy(np.ascontiguousarray(slots)))
+        md["slots"][T:].fill_(-1)
+        return AttentionMetadata(num_actual_tokens=T, max_query_len=max_query_len, query_start_loc=md["qsl"][:B + 1],
+                                 max_seq_len=int(max_seq_len if max_seq_len is not None else seq_lens.max()),
+                                 seq_lens=md["seq"][:B], block_table=md["bt"][:B], slot_mapping=md["slots"][:T],
+                                 query_start_loc_cpu=qsl, seq_lens_cpu=seq_lens)
 
     # ---- the stock step (what the plugin's execute_model replaces) ----------------------------------
     @torch.inference_mode()
@@ -310,6 +340,24 @@ class GPUModelRunner:
                    is_profile: bool = False):
         which = "shift" if (getattr(self, "shift_model", None) is not None and self.model is self.shift_model) else "base"
         self.dummy_runs.append((num_tokens, which, get_tp_group().world_size, is_profile))
+        if not self.execute_dummy_runs:
+            return None
+        # vLLM's dummy batch: min(num_tokens, max_num_reqs) requests sharing the tokens evenly (the last takes the rest)
+        num_reqs = min(num_tokens, self.max_num_reqs)
+        per = np.full(num_reqs, num_tokens // num_reqs, dtype=np.int32)
+        per[-1] += num_tokens % num_reqs
+        attn_metadata = None
+        if capture_attn_cudagraph:
+            assert self._md is not None, "capture_attn_cudagraph needs full_cuda_graph"
+            qsl = np.zeros(num_reqs + 1, dtype=np.int32)
+            np.cumsum(per, out=qsl[1:])
+            meta = self._fill_persistent_metadata(qsl, per.copy(), np.zeros((num_reqs, self._md["bt"].shape[1]), np.int32),
+                                                  np.full(num_tokens, -1, np.int64), int(per.max()),
+                                                  max_seq_len=self.max_model_len)
+            attn_metadata = {name: meta for name in self.compilation_config.static_forward_context}
+        with set_forward_context(attn_metadata, self.vllm_config, num_tokens=num_tokens):
+            return self.model(input_ids=self.input_ids[:num_tokens], positions=self.positions[:num_tokens],
+                              intermediate_tensors=None, inputs_embeds=None)
 
     def capture_model(self) -> None:
         for n in reversed(self.cudagraph_batch_sizes):

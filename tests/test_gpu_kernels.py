@@ -327,7 +327,7 @@ def test_verify_attention_head_size_64(cfg):
     dict(B=4, Hq=32, Hkv=8, D=128, q_lens=[4, 33, 2, 9], ctxs=[900, 1300, 64, 700], bs=32, window=200, sinks=True, fp8=True),
     dict(B=3, Hq=16, Hkv=2, D=128, q_lens=[1, 1, 1], ctxs=[31, 32, 33], bs=16, window=32, sinks=True),    # window == a tile, contexts around it
     dict(B=2, Hq=8, Hkv=2, D=128, q_lens=[5, 2], ctxs=[5, 2], bs=16, window=3, sinks=True),              # window shorter than the draft; ctx == q_len
-    dict(B=2, Hq=8, Hkv=8, D=128, q_lens=[3, 1], ctxs=[4000, 2500], bs=16, window=0, sinks=True),         # sinks over many splits (counted once)
+    dict(B=2, Hq=8, Hkv=8, D=128, q_lens=[3, 1], ctxs=[4000, 2500], bs=16, window=0, sinks=True, sink_shift=8.0),   # sinks over many splits (counted once)
 ])
 def test_verify_attention_sliding_window_and_sinks(cfg):
     """gpt-oss layers (BASELINE configs[4]): the sliding-window bound and the per-head sink term, against the fp32 oracle
@@ -338,7 +338,7 @@ def test_verify_attention_sliding_window_and_sinks(cfg):
     D = cfg["D"]
     q, kc, vc, bt, qsl = _attn_case(cfg["B"], cfg["Hq"], cfg["Hkv"], D, cfg["q_lens"], cfg["ctxs"], cfg["bs"], seed=31)
     g = torch.Generator().manual_seed(77)
-    sinks = (torch.randn(cfg["Hq"], generator=g) * 3).float() if cfg["sinks"] else None
+    sinks = (torch.randn(cfg["Hq"], generator=g) * 3 + cfg.get("sink_shift", 0.0)).float() if cfg["sinks"] else None
     ks = vs = 1.0
     kw = {}
     if cfg.get("fp8"):
