@@ -115,6 +115,7 @@ _SIGNATURES = {
     "aic_quantize_fp8_per_tensor": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "aic_lstm_padding_size": (c_int, [c_int]),
     "aic_lstm_propose": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "aic_debug_lstm_fused": (c_int, [c_int]),
     "aic_lstm_begin": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "aic_lstm_head": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "aic_verify_attention_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
@@ -133,6 +134,10 @@ _SIGNATURES = {
                                          c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                          c_int, c_float, c_void_p, c_int64, c_void_p, c_size_t, c_int, c_void_p, c_int,
                                          c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "aic_step_build": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
+                               c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "aic_step_parse": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                               c_void_p]),
     "aic_ulysses_pack_qkv": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int,
                                      c_int, c_int, c_void_p]),
     "aic_ulysses_split_qkv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

@@ -27,6 +27,7 @@
 //     workgroup and batch row.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <vector>
 
@@ -218,23 +219,51 @@ __device__ __forceinline__ uint4 ld_stream16(const uint4* p) {
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-template <bool FP8, int MT, int EPI>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
-skinny_gemm_kernel(const uint4* __restrict__ W, const uint4* __restrict__ X, int n_rowtiles, int steps_total,
-                   int steps_per_split, float* __restrict__ part, int n_cols_out, const float* __restrict__ x_scale,
-                   float w_scale, int n_valid_rows, int row_offset, float* __restrict__ best_val,
-                   int32_t* __restrict__ best_idx) {
+// XQ (fp8 only): the activation operand is read as bf16 (fragment-major, X) and quantised to e4m3 on its way into the LDS
+// tile with the dynamic per-tensor scale max(amax / 448, 2^-9 / 448) taken from *amax_bits — the arithmetic of
+// quant_act_kernel (fp8.py:303-308), unit for unit, without its launch and without the fp8 copy of the activations.
+struct GemmArgs {
+  const uint4* W;
+  const uint4* X;
+  int n_rowtiles, steps_total, steps_per_split;
+  float* part;
+  int n_cols_out;
+  const float* x_scale;
+  float w_scale;
+  int n_valid_rows, row_offset;
+  float* best_val;
+  int32_t* best_idx;
+  const unsigned int* amax_bits;
+};
+
+template <bool FP8, int MT, int EPI, bool XQ>
+__device__ __forceinline__ void skinny_gemm_body(const GemmArgs& A, uint4 (*lds)[kChunkSteps * MT * 64], const int bx,
+                                                 const int by) {
+  static_assert(!XQ || (FP8 && MT <= 2), "on-the-fly activation quantisation: fp8 head, at most 32 rows");
   constexpr int S = kChunkSteps;
   constexpr int XV = S * MT * 64 / 256;  // uint4 per thread per activation chunk ( = MT )
-  __shared__ uint4 lds[2][S * MT * 64];
+  const uint4* __restrict__ W = A.W;
+  const uint4* __restrict__ X = A.X;
+  const int n_rowtiles = A.n_rowtiles, steps_total = A.steps_total, steps_per_split = A.steps_per_split;
+  float* __restrict__ part = A.part;
+  const int n_cols_out = A.n_cols_out;
+  const float w_scale = A.w_scale;
+  const int n_valid_rows = A.n_valid_rows, row_offset = A.row_offset;
+  float* __restrict__ best_val = A.best_val;
+  int32_t* __restrict__ best_idx = A.best_idx;
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const int rt = blockIdx.x * 4 + wave;
-  const int split = blockIdx.y;
+  const int rt = bx * 4 + wave;
+  const int split = by;
   const int ks0 = split * steps_per_split;
   const int n_chunks = steps_per_split / S;
   const bool live = rt < n_rowtiles;
+  float xq_scale = 1.0f, xq_inv = 1.0f;
+  if (XQ) {
+    xq_scale = fmaxf(__uint_as_float(*A.amax_bits) / 448.0f, 1.0f / (448.0f * 512.0f));
+    xq_inv = 1.0f / xq_scale;
+  }
 
   const uint4* a_ptr = W + (static_cast<int64_t>(live ? rt : 0) * steps_total + ks0) * 64 + lane;
   const uint4* x_ptr = X + static_cast<int64_t>(ks0) * MT * 64 + tid;
@@ -243,8 +272,24 @@ skinny_gemm_kernel(const uint4* __restrict__ W, const uint4* __restrict__ X, int
 #pragma unroll
   for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  uint4 xr0, xr1, xr2, xr3;  // XV = MT <= 4 of them are live
+  uint4 xr0, xr1, xr2, xr3;  // XV = MT <= 4 of them are live (XQ: two bf16 units per fp8 unit, XV <= 2)
   (void)xr1; (void)xr2; (void)xr3;
+  // XQ: fp8 unit U = ((kp * MT + mt) * 64 + g * 16 + mm) <- bf16 units (row mt*16 + mm, k8 = (kp*64 + 16 g) / 8 and + 1)
+  auto xq_src = [&](int64_t U) -> int64_t {
+    const int mm = static_cast<int>(U & 15), g = static_cast<int>((U >> 4) & 3);
+    const int64_t t = U >> 6;
+    const int mt_ = static_cast<int>(t % MT);
+    const int kp = static_cast<int>(t / MT);
+    return xunit_bf16(mt_ * 16 + mm, (kp * 64 + 16 * g) / 8, MT);
+  };
+  // (no arrays: a dword holds bf16 values 2 i (low half) and 2 i + 1 (high half); bf16 -> f32 is a 16-bit shift)
+  auto q2 = [&](uint32_t a, uint32_t b) -> uint32_t {
+    return pack4_fp8(clamp448(__uint_as_float(a << 16) * xq_inv), clamp448(__uint_as_float(a & 0xffff0000u) * xq_inv),
+                     clamp448(__uint_as_float(b << 16) * xq_inv), clamp448(__uint_as_float(b & 0xffff0000u) * xq_inv));
+  };
+  auto xq_pack = [&](const uint4& lo, const uint4& hi) -> uint4 {
+    return make_uint4(q2(lo.x, lo.y), q2(lo.z, lo.w), q2(hi.x, hi.y), q2(hi.z, hi.w));
+  };
   uint4 a0_0, a0_1, a0_2, a0_3, a1_0, a1_1, a1_2, a1_3, a2_0, a2_1, a2_2, a2_3, a3_0, a3_1, a3_2, a3_3;
   // weights are read once per launch (and the next launch's are long gone from the caches): non-temporal loads
 #define AIC_LOAD_A(set_, c_)                                              \
@@ -256,20 +301,33 @@ skinny_gemm_kernel(const uint4* __restrict__ W, const uint4* __restrict__ X, int
     set_##_3 = ld_stream16(p_ + 192);                                      \
   }
 #define AIC_LOAD_X(c_)                                                        \
-  {                                                                           \
+  { if (XQ) {                                                                 \
+    const int64_t u0_ = (static_cast<int64_t>(ks0) + static_cast<int64_t>(c_) * S) * MT * 64 + tid; \
+    const int64_t b0_ = xq_src(u0_);                                          \
+    xr0 = X[b0_];                                                             \
+    xr1 = X[b0_ + 16];      /* k8 + 1 of the same row: 16 units on (k8 & 3 is 0 or 2 here) */ \
+    if (XV > 1) {                                                             \
+      const int64_t b1_ = xq_src(u0_ + 256);                                  \
+      xr2 = X[b1_];                                                           \
+      xr3 = X[b1_ + 16];                                                      \
+    }                                                                         \
+  } else {                                                                    \
     const uint4* xp_ = x_ptr + static_cast<int64_t>(c_) * S * MT * 64;        \
     xr0 = xp_[0];                                                             \
     if (XV > 1) xr1 = xp_[256];                                               \
     if (XV > 2) xr2 = xp_[512];                                               \
     if (XV > 3) xr3 = xp_[768];                                               \
-  }
+  } }
 #define AIC_STORE_X(buf_)                    \
-  {                                          \
+  { if (XQ) {                                \
+    lds[buf_][tid] = xq_pack(xr0, xr1);      \
+    if (XV > 1) lds[buf_][256 + tid] = xq_pack(xr2, xr3); \
+  } else {                                   \
     lds[buf_][tid] = xr0;                    \
     if (XV > 1) lds[buf_][256 + tid] = xr1;  \
     if (XV > 2) lds[buf_][512 + tid] = xr2;  \
     if (XV > 3) lds[buf_][768 + tid] = xr3;  \
-  }
+  } }
 #define AIC_MMA_STEP(areg_, s_, buf_)                                                                             \
   _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                             \
     const uint4 b = lds[buf_][((s_) * MT + mt) * 64 + lane];                                                      \
@@ -331,7 +389,7 @@ skinny_gemm_kernel(const uint4* __restrict__ W, const uint4* __restrict__ X, int
     // the K loop ended with a barrier: the staging buffer is free to carry the cross-wave reduction
     float(*s_val)[MT * 16] = reinterpret_cast<float(*)[MT * 16]>(&lds[0][0]);
     int(*s_idx)[MT * 16] = reinterpret_cast<int(*)[MT * 16]>(&lds[1][0]);
-    const float sc = FP8 ? (*x_scale) * w_scale : 1.0f;
+    const float sc = FP8 ? (XQ ? xq_scale : *A.x_scale) * w_scale : 1.0f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       float bv = -INFINITY;
@@ -371,10 +429,46 @@ skinny_gemm_kernel(const uint4* __restrict__ W, const uint4* __restrict__ X, int
           bi = oi;
         }
       }
-      best_val[static_cast<int64_t>(blockIdx.x) * (MT * 16) + tid] = bv;
-      best_idx[static_cast<int64_t>(blockIdx.x) * (MT * 16) + tid] = bi == 0x7fffffff ? 0x7fffffff : bi + row_offset;
+      best_val[static_cast<int64_t>(bx) * (MT * 16) + tid] = bv;
+      best_idx[static_cast<int64_t>(bx) * (MT * 16) + tid] = bi == 0x7fffffff ? 0x7fffffff : bi + row_offset;
     }
   }
+}
+
+template <bool FP8, int MT, int EPI>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+skinny_gemm_kernel(const uint4* __restrict__ W, const uint4* __restrict__ X, int n_rowtiles, int steps_total,
+                   int steps_per_split, float* __restrict__ part, int n_cols_out, const float* __restrict__ x_scale,
+                   float w_scale, int n_valid_rows, int row_offset, float* __restrict__ best_val,
+                   int32_t* __restrict__ best_idx) {
+  __shared__ uint4 lds[2][kChunkSteps * MT * 64];
+  const GemmArgs A{W, X, n_rowtiles, steps_total, steps_per_split, part, n_cols_out, x_scale, w_scale, n_valid_rows,
+                   row_offset, best_val, best_idx, nullptr};
+  skinny_gemm_body<FP8, MT, EPI, false>(A, lds, blockIdx.x, blockIdx.y);
+}
+
+// The LM head of draft head h and the gate projection of head h + 1 in ONE launch: both read the state h_h and neither
+// needs the other's result (the token of head h enters head h + 1 in the cell, after the projection), so the 134 MB gate
+// projection — alone a 30 us launch at 4.4 TB/s, a third of it ramp and tail — rides inside the 0.5-1 GB head launch.
+// Workgroups [0, gate_bx * gate_by) run the gate body (split-K partials), the rest the head body (arg-max epilogue;
+// fp8 head: activations quantised on the way into LDS).
+template <bool FP8H, int MT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+skinny_pair_kernel(GemmArgs G, GemmArgs Hd, int gate_bx, int gate_by) {
+  __shared__ uint4 lds[2][kChunkSteps * MT * 64];
+  const int b = blockIdx.x, n_gate = gate_bx * gate_by;
+  if (b < n_gate)
+    skinny_gemm_body<false, MT, 0, false>(G, lds, b % gate_bx, b / gate_bx);
+  else
+    skinny_gemm_body<FP8H, MT, 1, FP8H>(Hd, lds, b - n_gate, 0);
+}
+
+// the head alone with on-the-fly activation quantisation (last draft head of the fused path)
+template <int MT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+skinny_head_xq_kernel(GemmArgs Hd) {
+  __shared__ uint4 lds[2][kChunkSteps * MT * 64];
+  skinny_gemm_body<true, MT, 1, true>(Hd, lds, blockIdx.x, 0);
 }
 
 // ---- LSTM cell: everything between the gate projection and the LM head (arctic_speculator.py:667-689)
@@ -409,13 +503,75 @@ __device__ __forceinline__ float cell_added(const CellArgs& a, int m, const uint
 // phase A, workgroup (row m, part q): new cell state of columns [q Ds/4, (q+1) Ds/4) and their share of its mean square.
 // The first normalisation's row sum is computed by every part for itself (4 Ds partial reads from L2: nothing next to a
 // cross-workgroup step).
+// Fused draft path (PrevArgmax.best_val != nullptr): the arg-max over the previous head's per-workgroup partials is
+// finished HERE — every part of a row reduces the same n_blocks candidates to the same token (ties to the lowest index, so
+// the order of the reduction does not matter), part 0 publishes it (tokens[m], the draft's output column) — instead of in
+// a launch of its own between the LM head and this cell.
+struct PrevArgmax {
+  const float* best_val;      // [n_blocks][m_pad] or nullptr: the token is tokens[m] already
+  const int32_t* best_idx;
+  int n_blocks;
+  int32_t* tokens;            // [m_pad] written by part 0
+  int64_t* out_tokens;        // [batch][out_stride] or nullptr
+  float* out_vals;
+  int out_stride, out_col;
+};
+
+__device__ __forceinline__ void block_argmax(float& bv, int& bi, float* s_v, int* s_i) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(bv, off);
+    const int oi = __shfl_xor(bi, off);
+    if (ov > bv || (ov == bv && oi < bi)) {
+      bv = ov;
+      bi = oi;
+    }
+  }
+  const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_v[wave] = bv;
+    s_i[wave] = bi;
+  }
+  __syncthreads();
+  bv = s_v[0];
+  bi = s_i[0];
+  for (int w = 1; w < n_waves; ++w)
+    if (s_v[w] > bv || (s_v[w] == bv && s_i[w] < bi)) {
+      bv = s_v[w];
+      bi = s_i[w];
+    }
+  __syncthreads();
+}
+
 __global__ void __launch_bounds__(1024)
 lstm_cell_a_kernel(CellArgs a, const uint16_t* __restrict__ cln_w, const uint16_t* __restrict__ cln_b,
-                   uint16_t* __restrict__ cell, float* __restrict__ ss2_part) {
+                   uint16_t* __restrict__ cell, float* __restrict__ ss2_part, PrevArgmax pa) {
   __shared__ float sh[16];
+  __shared__ float s_v[16];
+  __shared__ int s_i[16];
   const int m = blockIdx.x, q = blockIdx.y, Ds = a.Ds;
   if (m >= a.batch) return;
-  int tok = a.tokens[m];
+  int tok;
+  if (pa.best_val != nullptr) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int b = threadIdx.x; b < pa.n_blocks; b += blockDim.x) {
+      const float v = pa.best_val[static_cast<int64_t>(b) * a.m_pad + m];
+      const int i = pa.best_idx[static_cast<int64_t>(b) * a.m_pad + m];
+      if (v > bv || (v == bv && i < bi)) {
+        bv = v;
+        bi = i;
+      }
+    }
+    block_argmax(bv, bi, s_v, s_i);
+    tok = bi;
+    if (q == 0 && threadIdx.x == 0) {
+      pa.tokens[m] = bi;
+      if (pa.out_tokens) pa.out_tokens[static_cast<int64_t>(m) * pa.out_stride + pa.out_col] = bi;
+      if (pa.out_vals) pa.out_vals[static_cast<int64_t>(m) * pa.out_stride + pa.out_col] = bv;
+    }
+  } else {
+    tok = a.tokens[m];
+  }
   if (tok < 0 || tok >= a.vocab_rows) tok = 0;  // never read outside the table
   const uint16_t* z = a.emb + static_cast<int64_t>(tok) * Ds;
 
@@ -725,7 +881,7 @@ static int run_head(aic_lstm* m, int head_index, hipStream_t s, int64_t* out_tok
     CellArgs ca{m->part, splits, mpad, B, m->tokens, static_cast<const uint16_t*>(m->w.forget_emb), 0x7fffffff, m->alpha, Ds};
     hipLaunchKernelGGL(lstm_cell_a_kernel, dim3(mpad, kCellParts), dim3(1024), 0, s, ca,
                        static_cast<const uint16_t*>(m->w.cell_ln_w), static_cast<const uint16_t*>(m->w.cell_ln_b), m->cell,
-                       m->ss2_part);
+                       m->ss2_part, PrevArgmax{});
     hipLaunchKernelGGL(lstm_cell_b_kernel, dim3(mpad, kCellParts), dim3(128), 0, s, ca,
                        static_cast<const uint16_t*>(m->w.state_ln_w), static_cast<const uint16_t*>(m->w.state_ln_b),
                        static_cast<const uint16_t*>(m->cell), m->ss2_part, mt, m->h_bf16, m->amax + head_index);
@@ -986,6 +1142,88 @@ int aic_lstm_head(aic_lstm* m, int head_index, const int32_t* last_tokens, int b
   return run_head(m, head_index, s, out_tokens, 1, 0, out_vals);
 }
 
+// The whole k-head draft of the LSTM speculator in 3 k + 3 launches (12 at k = 3; the head-by-head form takes 5-6 per
+// head + 1): the gate projection of head h + 1 shares a launch with the LM head of head h (skinny_pair_kernel), the arg-max
+// over the LM head's partials is finished inside the next cell launch (or once at the end), and the fp8 head quantises its
+// activations on the way into LDS.  Same arithmetic as run_head() operation by operation: bit-identical tokens.
+static int propose_fused(aic_lstm* m, int k, int64_t* out_tokens, float* out_vals, hipStream_t s) {
+  const aic_lstm_config& c = m->cfg;
+  const int mt = m->cur_mt, mpad = mt * 16, B = m->cur_batch, Ds = c.inner_dim;
+  const bool fp8 = m->head8_t && mpad <= c.head_fp8_max_batch;
+  auto gate_args = [&](int head, int* splits_out) {
+    const bool first = head == 0;
+    const int K = first ? c.input_hidden_dim : Ds;
+    const int steps_total = K / 32;
+    int splits = m->gate_splits;
+    while (splits > 1 && (steps_total % (splits * kChunkSteps) != 0)) --splits;
+    *splits_out = splits;
+    return GemmArgs{first ? m->proj0_t : m->proj1_t, first ? m->x0 : m->h_bf16, m->gate_rowtiles, steps_total,
+                    steps_total / splits, m->part, 4 * Ds, nullptr, 1.0f, 0, 0, nullptr, nullptr, nullptr};
+  };
+  auto head_args = [&](int head) {
+    if (fp8)
+      return GemmArgs{m->head8_t, m->h_bf16, m->head_rowtiles, Ds / 64, Ds / 64, nullptr, 0, nullptr, m->head8_scale,
+                      c.vocab_size, c.vocab_offset, m->best_val, m->best_idx, m->amax + head};
+    return GemmArgs{m->head_t, m->h_bf16, m->head_rowtiles, Ds / 32, Ds / 32, nullptr, 0, nullptr, 1.0f, c.vocab_size,
+                    c.vocab_offset, m->best_val, m->best_idx, nullptr};
+  };
+  int splits = 1, rc;
+  {
+    const GemmArgs G = gate_args(0, &splits);
+    dim3 grid((m->gate_rowtiles + 3) / 4, splits);
+    rc = launch_gemm<false, 0>(mt, grid, s, G.W, G.X, G.n_rowtiles, G.steps_total, G.steps_per_split, G.part, G.n_cols_out,
+                               nullptr, 1.0f, 0, 0, nullptr, nullptr);
+    if (rc != AIC_OK) return rc;
+  }
+  for (int h = 0; h < k; ++h) {
+    CellArgs ca{m->part, splits, mpad, B, m->tokens, static_cast<const uint16_t*>(m->w.forget_emb), 0x7fffffff, m->alpha, Ds};
+    PrevArgmax pa{};
+    if (h > 0) pa = PrevArgmax{m->best_val, m->best_idx, m->head_blocks, m->tokens, out_tokens, out_vals, k, h - 1};
+    hipLaunchKernelGGL(lstm_cell_a_kernel, dim3(mpad, kCellParts), dim3(1024), 0, s, ca,
+                       static_cast<const uint16_t*>(m->w.cell_ln_w), static_cast<const uint16_t*>(m->w.cell_ln_b), m->cell,
+                       m->ss2_part, pa);
+    hipLaunchKernelGGL(lstm_cell_b_kernel, dim3(mpad, kCellParts), dim3(128), 0, s, ca,
+                       static_cast<const uint16_t*>(m->w.state_ln_w), static_cast<const uint16_t*>(m->w.state_ln_b),
+                       static_cast<const uint16_t*>(m->cell), m->ss2_part, mt, m->h_bf16, m->amax + h);
+    if ((rc = launch_status("lstm_cell_kernel")) != AIC_OK) return rc;
+    const GemmArgs Hd = head_args(h);
+    if (h + 1 < k) {
+      const GemmArgs G = gate_args(h + 1, &splits);
+      const int gate_bx = (m->gate_rowtiles + 3) / 4;
+      const dim3 grid(static_cast<unsigned>(gate_bx * splits + m->head_blocks));
+#define AIC_PAIR(FP8H_, MT_) \
+  hipLaunchKernelGGL((skinny_pair_kernel<FP8H_, MT_>), grid, dim3(256), 0, s, G, Hd, gate_bx, splits)
+      if (fp8) {
+        if (mt == 1) AIC_PAIR(true, 1); else AIC_PAIR(true, 2);
+      } else {
+        if (mt == 1) AIC_PAIR(false, 1); else if (mt == 2) AIC_PAIR(false, 2); else AIC_PAIR(false, 4);
+      }
+#undef AIC_PAIR
+      if ((rc = launch_status("skinny_pair_kernel")) != AIC_OK) return rc;
+    } else if (fp8) {
+      if (mt == 1)
+        hipLaunchKernelGGL((skinny_head_xq_kernel<1>), dim3(m->head_blocks), dim3(256), 0, s, Hd);
+      else
+        hipLaunchKernelGGL((skinny_head_xq_kernel<2>), dim3(m->head_blocks), dim3(256), 0, s, Hd);
+      if ((rc = launch_status("skinny_head_xq_kernel")) != AIC_OK) return rc;
+    } else {
+      rc = launch_gemm<false, 1>(mt, dim3(m->head_blocks, 1), s, Hd.W, Hd.X, Hd.n_rowtiles, Hd.steps_total,
+                                 Hd.steps_per_split, nullptr, 0, nullptr, 1.0f, Hd.n_valid_rows, Hd.row_offset,
+                                 Hd.best_val, Hd.best_idx);
+      if (rc != AIC_OK) return rc;
+    }
+  }
+  hipLaunchKernelGGL(argmax_finish_kernel, dim3(mpad), dim3(256), 0, s, m->best_val, m->best_idx, m->head_blocks, mpad, B,
+                     m->tokens, out_tokens, k, k - 1, out_vals);
+  return launch_status("argmax_finish_kernel");
+}
+
+static std::atomic<int> g_lstm_fused{1};
+int aic_debug_lstm_fused(int on) {
+  g_lstm_fused.store(on);
+  return AIC_OK;
+}
+
 int aic_lstm_propose(aic_lstm* m, const void* hidden, const int32_t* hidden_index, const int32_t* last_tokens,
                      int batch, int num_predict_tokens, int64_t* out_tokens, float* out_vals, void* stream) {
   AIC_REQUIRE(m && hidden && last_tokens && out_tokens, "null argument to aic_lstm_propose");
@@ -993,6 +1231,7 @@ int aic_lstm_propose(aic_lstm* m, const void* hidden, const int32_t* hidden_inde
   int rc = lstm_begin(m, hidden, hidden_index, last_tokens, batch, stream);
   if (rc != AIC_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!m->mlp && g_lstm_fused.load() != 0) return propose_fused(m, num_predict_tokens, out_tokens, out_vals, s);
   for (int h = 0; h < num_predict_tokens; ++h) {
     rc = run_head(m, h, s, out_tokens, num_predict_tokens, h, out_vals);
     if (rc != AIC_OK) return rc;

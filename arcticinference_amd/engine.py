@@ -22,6 +22,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
+from . import _native as N
 from . import ops
 from .speculator import ArcticLSTMSpeculator
 from .suffix_cache import SuffixCache, SuffixSpecResult
@@ -177,6 +178,10 @@ class HotPathEngine:
         self.drafter = speculator
         self.ulysses = ulysses
         self._indexing = proposal_indexing(spec)
+        # index build / parse of a step: native (csrc/engine_host.cpp) unless AIC_ENGINE_NUMPY=1 (the numpy form, kept as the
+        # A/B reference)
+        import os
+        self._native_index = os.environ.get("AIC_ENGINE_NUMPY", "0") != "1"
         self.sp = 1 if ulysses is None else ulysses.sp_size
         self.suffix_cache = SuffixCache(spec.suffix_cache_max_depth) if (
             spec.enable_suffix_decoding or spec.method == "suffix") else None
@@ -310,6 +315,12 @@ class HotPathEngine:
             for which in ("A", "B"):
                 pin = torch.empty(1 << 17, dtype=torch.uint8).pin_memory()
                 L.stage[which] = (pin, torch.empty(pin.numel(), dtype=torch.uint8, device=self.device))
+            # scratch of the native index build / parse (aic_step_build, aic_step_parse)
+            L.offs_a, L.offs_b = np.zeros(5, np.int64), np.zeros(7, np.int64)
+            L.totals, L.ctx_sum = np.zeros(8, np.int64), np.zeros(1, np.int64)
+            L.n_emit = np.zeros(self.max_num_seqs, np.int32)
+            L.flat_emit = np.zeros(self.max_num_seqs * (MAX_SPEC_LEN + 2), np.int32)
+            L.parse_total = np.zeros(1, np.int64)
             lanes[lane] = L
         return lanes[lane]
 
@@ -333,6 +344,76 @@ class HotPathEngine:
             return None
         reqs = [rq[i] for i in live]
         n_draft = self.n_draft[live]
+        G = self.hq_local // self.hkv_local
+        prev_lstm = L.lstm_prev
+        if not self._native_index:
+            return self._begin_numpy(next_truth, L, live, reqs, n_draft, G, _mark)
+        # every index array of the step in ONE native call, written straight into the lane's two pinned staging buffers
+        # (A: what the KV write and the attention launches need; B: what only the acceptance needs)
+        pinA, devA = L.stage["A"]
+        pinB, devB = L.stage["B"]
+        lib = N.lib()
+        while True:
+            rc = lib.aic_step_build(B, live.ctypes.data, self.num_tokens.ctypes.data, self.n_draft.ctypes.data,
+                                    self.draft_ids.ctypes.data, MAX_SPEC_LEN,
+                                    self.draft_row.ctypes.data if prev_lstm is not None else None,
+                                    0 if prev_lstm is None else int(prev_lstm.shape[1]), self._bt_host.ctypes.data,
+                                    self.blocks_per_seq, s.block_size, G, pinA.data_ptr(), pinA.numel(), pinB.data_ptr(),
+                                    pinB.numel(), L.offs_a.ctypes.data, L.offs_b.ctypes.data, L.totals.ctypes.data,
+                                    L.ctx_sum.ctypes.data)
+            if rc == 0:
+                break
+            if "staging buffers too small" not in lib.aic_last_error().decode():
+                N.check(rc)
+            for which in ("A", "B"):       # grow and retry (first steps only)
+                pin = torch.empty(2 * L.stage[which][0].numel(), dtype=torch.uint8).pin_memory()
+                L.stage[which] = (pin, torch.empty(pin.numel(), dtype=torch.uint8, device=dev))
+            pinA, devA = L.stage["A"]
+            pinB, devB = L.stage["B"]
+        T, max_q, max_ctx, n_short_reqs, D, F, bytes_a, bytes_b = (int(x) for x in L.totals)
+        oa, ob = L.offs_a, L.offs_b
+        if getattr(self, "qlen_hist", None) is not None:      # diagnostic (bench.py --qlen-hist): query lengths seen
+            self.qlen_hist += np.bincount(n_draft + 1, minlength=len(self.qlen_hist))[:len(self.qlen_hist)]
+        devA[:bytes_a].copy_(pinA[:bytes_a], non_blocking=True)
+        view = lambda buf, off, n, dt, isz: buf[off:off + n * isz].view(dt)
+        d_seq = view(devA, int(oa[0]), B, torch.int32, 4)
+        d_qsl = view(devA, int(oa[1]), B + 1, torch.int32, 4)
+        slots = view(devA, int(oa[2]), B, torch.int64, 8)
+        d_slots = view(devA, int(oa[3]), T, torch.int64, 8)
+        order_dev = view(devA, int(oa[4]), B, torch.int32, 4)
+        bt = self.block_table.index_select(0, slots) if B != self.max_num_seqs else self.block_table
+        self._write_kv(d_slots, T)
+        _mark('host_prepare')
+        self._req_split = (order_dev[:n_short_reqs], n_short_reqs, order_dev[n_short_reqs:], B - n_short_reqs)
+        self._stream = int(torch.cuda.current_stream().cuda_stream)   # looked up once per step, not once per layer
+        self._attention_layers(T, bt, d_seq, d_qsl, max_q, max_ctx)
+        self.last_ctx_sum = int(L.ctx_sum[0])
+        _mark('enqueue_attention')
+        # ---- staging B (the GPU is busy with the attention launches from here on): only the synthetic target's tokens
+        # are missing from it — row (request i, position p) gets the target's token for that position
+        ql = (n_draft + 1).tolist()
+        plant = pinB.numpy()[int(ob[2]):int(ob[2]) + 8 * T].view(np.int64)
+        at = 0
+        for i, r in enumerate(reqs):
+            plant[at:at + ql[i]] = next_truth(r, ql[i])
+            at += ql[i]
+        devB[:bytes_b].copy_(pinB[:bytes_b], non_blocking=True)
+        d_draft = view(devB, int(ob[0]), D, torch.int32, 4)
+        d_cu = view(devB, int(ob[1]), B, torch.int32, 4)
+        d_plant = view(devB, int(ob[2]), T, torch.int64, 8)
+        d_trows = view(devB, int(ob[3]), D, torch.int64, 8)
+        d_brows = view(devB, int(ob[4]), B, torch.int64, 8)
+        if F:
+            d_fpos, d_fsrc = view(devB, int(ob[5]), F, torch.int64, 8), view(devB, int(ob[6]), F, torch.int64, 8)
+            d_draft.index_copy_(0, d_fpos, prev_lstm.reshape(-1).index_select(0, d_fsrc).to(torch.int32))
+        _mark('stage_acceptance')
+        return self._begin_accept(L, live, reqs, B, T, n_draft, max(max_q - 1, 1), d_draft, d_cu, d_plant, d_trows, d_brows,
+                                  _mark)
+
+    def _begin_numpy(self, next_truth, L, live, reqs, n_draft, G, _mark):
+        """begin() with the index arrays built by numpy (AIC_ENGINE_NUMPY=1: the A/B reference of the native build)."""
+        s, dev = self.shape, self.device
+        B = len(live)
         q_len = n_draft + 1
         T = int(q_len.sum())
         qsl = np.zeros(B + 1, dtype=np.int32)
@@ -350,7 +431,6 @@ class HotPathEngine:
         # while the GPU is already attending (rocprofv3 timeline of the r02 bench: 0.58 ms of GPU idle sat between the
         # suffix kernels of one step and the staging copy of the next; building B first was a third of it).
         slot_map = self._slot_mapping(live, ntok, q_len, qsl, T)
-        G = self.hq_local // self.hkv_local
         order, n_short_reqs = ops.split_order(q_len, G)            # short / long request lists of the attention call
         stA = self._stage(L, "A", [(ctx, np.int32), (qsl, np.int32), (live, np.int64), (slot_map, np.int64), (order, np.int32)])
         d_seq, d_qsl, slots, d_slots, order_dev = stA
@@ -396,6 +476,14 @@ class HotPathEngine:
         if len(fill_pos):
             d_draft.index_copy_(0, d_fpos, prev_lstm.reshape(-1).index_select(0, d_fsrc).to(torch.int32))
         _mark('stage_acceptance')
+        return self._begin_accept(L, live, reqs, B, T, n_draft, int(max(n_draft.max(), 1)), d_draft, d_cu, d_plant, d_trows,
+                                  d_brows, _mark)
+
+    def _begin_accept(self, L, live, reqs, B, T, n_draft, max_spec, d_draft, d_cu, d_plant, d_trows, d_brows, _mark):
+        """(c)-(d) of begin(): acceptance on the planted verify logits, the accepted tokens on their way to the host, the
+        draft model behind them."""
+        from types import SimpleNamespace
+        spec = self.spec
         # (c) verify logits: plant, accept, un-plant
         lg = self.logits[:T]
         col = d_plant.unsqueeze(1)
@@ -403,7 +491,6 @@ class HotPathEngine:
         lg.scatter_(1, col, self._plant_col[:T])   # gather/scatter on device tensors only: nothing here may sync the stream
         # greedy sampler on the bonus rows and the target rows of the acceptance: both read in place from the [T, V] logits
         # through their row indices (bonus_logits_indices / target_logits_indices) inside one launch
-        max_spec = int(max(n_draft.max(), 1))
         rej = ops.rejection_sample(lg, d_draft, d_cu, None, max_spec, target_row_index=d_trows, bonus_row_index=d_brows)
         lg.scatter_(1, col, saved)
 
@@ -430,7 +517,7 @@ class HotPathEngine:
                                                        hidden_index=rej.hidden_index)
         _mark('enqueue_accept_and_draft')
         return SimpleNamespace(lane=L, live=live, reqs=reqs, B=B, n_draft=n_draft, out_pin=out_pin, rej=rej, lstm_out=lstm_out,
-                               use_lstm=use_lstm, ntok=ntok)
+                               use_lstm=use_lstm)
 
     def finish(self, c) -> List[List[int]]:
         """Host half of the step begun as `c`: returns the tokens emitted per request of that step."""
@@ -452,17 +539,29 @@ class HotPathEngine:
         out_host = out_pin.numpy()
         _mark('wait_gpu_accept')
 
-        # (e) host: parse, commit, update the suffix trees while the LSTM kernels run — whole-batch array operations
-        valid = (out_host != -1) & (out_host < s.vocab_size)                  # parse_output (:456-459)
-        n_emit = valid.sum(axis=1).astype(np.int32)
-        flat_emit = out_host[valid]                                            # row-major: request by request
-        n_total = len(flat_emit)
-        ntok = c.ntok
-        first = np.cumsum(n_emit) - n_emit
-        within = np.arange(n_total) - np.repeat(first, n_emit)
-        self.token_ids_cpu[np.repeat(live, n_emit), np.repeat(ntok, n_emit) + within] = flat_emit
-        ntok = ntok + n_emit
-        self.num_tokens[live] = ntok
+        # (e) host: parse, commit, update the suffix trees while the LSTM kernels run
+        if self._native_index:
+            # parse_output (:456-459) + the commit into token_ids_cpu / num_tokens (:469-486), one native call
+            N.check(N.lib().aic_step_parse(B, live.ctypes.data, out_host.ctypes.data, out_host.shape[1], s.vocab_size,
+                                           self.token_ids_cpu.ctypes.data, self.token_ids_cpu.shape[1],
+                                           self.num_tokens.ctypes.data, L.n_emit.ctypes.data, L.flat_emit.ctypes.data,
+                                           L.parse_total.ctypes.data))
+            n_total = int(L.parse_total[0])
+            n_emit = L.n_emit[:B].copy()
+            flat_emit = L.flat_emit[:n_total].copy()
+            ntok = self.num_tokens[live]
+            within = None
+        else:
+            valid = (out_host != -1) & (out_host < s.vocab_size)                  # parse_output (:456-459)
+            n_emit = valid.sum(axis=1).astype(np.int32)
+            flat_emit = out_host[valid]                                            # row-major: request by request
+            n_total = len(flat_emit)
+            ntok = self.num_tokens[live]
+            first = np.cumsum(n_emit) - n_emit
+            within = np.arange(n_total) - np.repeat(first, n_emit)
+            self.token_ids_cpu[np.repeat(live, n_emit), np.repeat(ntok, n_emit) + within] = flat_emit
+            ntok = ntok + n_emit
+            self.num_tokens[live] = ntok
         self.n_draft[live] = 0
         self.draft_row[live] = -1
         emitted = Emitted(flat_emit, n_emit)
@@ -480,6 +579,8 @@ class HotPathEngine:
         end_prop = ntok
         if self._indexing == INDEXING_REFERENCE:
             end_prop = ntok + n_emit
+            if within is None:
+                within = np.arange(n_total) - np.repeat(np.cumsum(n_emit) - n_emit, n_emit)
             pos = np.repeat(ntok, n_emit) + within
             keep = pos < self.max_model_len                  # :701-707: the write is cut at max_model_len
             self.token_ids_cpu[np.repeat(live, n_emit)[keep], pos[keep]] = flat_emit[keep]

@@ -480,6 +480,7 @@ def main():
         elapsed = float(t.item())
     import copy
     gen_total, stats_snapshot, timeline_snapshot = gen_tokens[0], copy.copy(eng.stats), dict(eng.timeline)
+    attn_bytes_timed = attn_bytes[0]            # (the legs below keep running steps: the timed region's bytes are these)
     replaced_total = replaced[0]
     steps_shift = ulysses.steps_shift if ulysses is not None else 0
     steps_sp = ulysses.steps_sp if ulysses is not None else 0
@@ -546,7 +547,7 @@ def main():
         st = stats_snapshot
         avg_launch_us = tot_us.value / max(launches.value, 1)
         # every launch of a lane's step moves that lane's bytes; n_lanes launches per layer and round
-        bytes_per_launch = attn_bytes[0] / max(args.steps * shape.num_layers * n_lanes, 1)
+        bytes_per_launch = attn_bytes_timed / max(args.steps * shape.num_layers * n_lanes, 1)
         achieved = bytes_per_launch / (avg_launch_us * 1e-6) / 1e9 if launches.value else 0.0
         # PMC-measured HBM bytes per launch: NOT measured in this run (counters need their own rocprofv3 --pmc passes) —
         # taken from the committed summary of those passes over this same command, and only for the workload they were

@@ -311,6 +311,10 @@ int aic_lstm_padding_size(int batch);
  *   out_vals: f32 [B][k] bf16-rounded max logit per head (for the TP arg-max exchange, :733-744), may be NULL */
 int aic_lstm_propose(aic_lstm* m, const void* hidden, const int32_t* hidden_index, const int32_t* last_tokens,
                      int batch, int num_predict_tokens, int64_t* out_tokens, float* out_vals, void* stream);
+/* debug aid: 1 (default) the whole-draft entry point of an LSTM speculator runs the fused schedule (LM head of head h and
+ * gate projection of head h + 1 in one launch, arg-max finished inside the next cell launch, fp8 activations quantised on
+ * the way into LDS: 3 k + 3 launches), 0 the head-by-head one (5-6 launches per head); both compute the same tokens. */
+int aic_debug_lstm_fused(int on);
 /* single-head entry points for the vocab-parallel (TP/SP > 1) loop, where an all-gather of
  * (value, index) sits between heads.  State lives in the handle. */
 int aic_lstm_begin(aic_lstm* m, const void* hidden, const int32_t* hidden_index, int batch, void* stream);
@@ -410,6 +414,19 @@ int aic_ulysses_pack_pair(const void* a, const void* b, int64_t a_stride, int64_
                           int parts, int a_width, int b_width, void* stream);
 int aic_ulysses_reorder_split_kv(const void* gathered, void* k, void* v, int n_chunk_rows, int sp, int kv_width,
                                  const int32_t* order /*host*/, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A4 (host)  Index arithmetic of one engine step for drivers that own the step (arcticinference_amd/engine.py), native:
+ *     what the reference's execute_model does in Python around the model call — query offsets, contexts, KV slots, target /
+ *     bonus rows of SpecDecodeMetadata (model_runner.py:394-404), parse_output + commit of the sampled ids (:456-486).
+ *     Pure host code (no device needed); layouts in csrc/engine_host.cpp.
+ * ---------------------------------------------------------------------------------------- */
+int aic_step_build(int n, const int64_t* live, const int32_t* num_tokens, const int32_t* n_draft, const int32_t* draft_ids,
+                   int draft_stride, const int64_t* draft_row, int lstm_k, const int32_t* block_table, int blocks_per_seq,
+                   int block_size, int group_size, void* stage_a, int64_t cap_a, void* stage_b, int64_t cap_b,
+                   int64_t* offs_a /*[5]*/, int64_t* offs_b /*[7]*/, int64_t* totals /*[8]*/, int64_t* ctx_sum);
+int aic_step_parse(int n, const int64_t* live, const int32_t* out, int width, int vocab, int32_t* token_ids,
+                   int64_t row_stride, int32_t* num_tokens, int32_t* n_emit, int32_t* flat_emit, int64_t* total);
 
 #ifdef __cplusplus
 }

@@ -812,6 +812,45 @@ def test_lstm_speculator_small(B, fp8):
     _check_tokens(got, want, logits, f"B={B} fp8={use_fp8}", ulps=4 if use_fp8 else 1, rerun=rerun)
 
 
+@pytest.mark.parametrize("B,fp8,Ds,H,V", [(3, False, 512, 768, 3000), (20, True, 512, 768, 3000), (20, False, 512, 768, 3000),
+                                           (64, True, 512, 768, 3000), (13, True, 1024, 512, 50000), (40, False, 1024, 1024, 50000)])
+def test_lstm_fused_schedule_equals_head_by_head(B, fp8, Ds, H, V):
+    """The whole-draft entry point's fused schedule (LM head of head h + gate projection of head h + 1 in one launch, the
+    arg-max finished inside the next cell launch, fp8 activations quantised on the way into LDS: 12 launches at k = 3) and the
+    head-by-head one (16-19) are the same arithmetic operation by operation: tokens AND bf16-rounded maximum logits are
+    bit-identical, with and without the hidden-state row index."""
+    import ctypes
+    from arcticinference_amd import _native as N
+    from arcticinference_amd.speculator import ArcticLSTMSpeculator, LSTMSpeculatorConfig, random_lstm_weights
+    cfg = LSTMSpeculatorConfig(vocab_size=V, input_hidden_dim=H, inner_dim=str(Ds), emb_dim=str(Ds), proj_dim=str(Ds),
+                               n_predict=3, num_lookahead_tokens=3)
+    m = ArcticLSTMSpeculator(cfg, max_num_seqs=64, device=DEV, quantize_lm_head=fp8)
+    m.load_weights(random_lstm_weights(cfg, seed=5, std=0.05).items())
+    g = torch.Generator().manual_seed(B)
+    hidden = torch.randn(2 * B, H, generator=g).to(torch.bfloat16).to(DEV)
+    ids = torch.randint(0, V, (B,), generator=g).to(torch.int32).to(DEV)
+    hidx = torch.randperm(2 * B, generator=g)[:B].to(torch.int32).to(DEV)
+    lib = N.lib()
+
+    def run(mode, index):
+        lib.aic_debug_lstm_fused(mode)
+        toks = torch.full((B, 3), -1, dtype=torch.int64, device=DEV)
+        vals = torch.full((B, 3), float("nan"), dtype=torch.float32, device=DEV)
+        N.check(lib.aic_lstm_propose(m._h, hidden.data_ptr(), index.data_ptr() if index is not None else None, ids.data_ptr(),
+                                     B, 3, toks.data_ptr(), vals.data_ptr(), N.current_stream_ptr()))
+        torch.cuda.synchronize()
+        return toks.cpu(), vals.cpu()
+
+    try:
+        for index in (None, hidx):
+            t0, v0 = run(0, index)
+            t1, v1 = run(1, index)
+            assert torch.equal(t0, t1) and torch.equal(v0, v1), (B, fp8, index is not None)
+            assert (t1 >= 0).all() and (t1 < V).all() and not torch.isnan(v1).any()
+    finally:
+        lib.aic_debug_lstm_fused(1)
+
+
 def test_lstm_speculator_full_size():
     """The 8B speculator's shapes (Ds = 4096, hidden 4096, vocab 128256), B = 8 rows, bf16 head: tokens against the
     CPU oracle (a few seconds of CPU GEMM)."""
