@@ -15,6 +15,7 @@
 // rules (strict >, earlier start wins; prompt tree wins ties against the global tree).
 #include <hip/hip_runtime.h>
 #include <chrono>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cstring>
@@ -177,7 +178,8 @@ suffix_select_kernel(const QueryRec* __restrict__ queries, int n_starts, int cap
                      const int32_t* __restrict__ scr_tok, const float* __restrict__ scr_prob,
                      int32_t* __restrict__ out_n, float* __restrict__ out_score,
                      int32_t* __restrict__ out_match, int32_t* __restrict__ out_tok,
-                     float* __restrict__ out_prob) {
+                     float* __restrict__ out_prob, int32_t* __restrict__ done_counter, int32_t* done_flag,
+                     int32_t epoch) {
   const int qi = blockIdx.x;
   const int lane = threadIdx.x;
   const int n = queries[qi].pattern_len;
@@ -221,6 +223,21 @@ suffix_select_kernel(const QueryRec* __restrict__ queries, int n_starts, int cap
     out_n[qi] = cnt;
     out_score[qi] = win_score;
     out_match[qi] = win_item >= 0 ? n - win_s : 0;
+  }
+  // zero-copy results (done_flag != nullptr): the outputs above went straight to pinned host memory; the workgroup that
+  // finishes last raises the flag the host is polling.  Every workgroup's stores are pushed out system-wide before it is
+  // counted, so the flag is never seen ahead of any of them.
+  if (done_flag != nullptr) {
+    __threadfence_system();
+    __syncthreads();
+    if (lane == 0) {
+      const int prev = atomicAdd(done_counter, 1);
+      if (prev == static_cast<int>(gridDim.x) - 1) {
+        atomicExch(done_counter, 0);        // ready for the next call
+        __threadfence_system();
+        __hip_atomic_store(done_flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
 }
 
@@ -303,6 +320,7 @@ class Mirror {
     if (dblob_) (void)hipFree(dblob_);
     if (dscr_) (void)hipFree(dscr_);
     if (pin_out_) (void)hipHostFree(pin_out_);
+    if (done_counter_) (void)hipFree(done_counter_);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
   }
@@ -511,7 +529,7 @@ class Mirror {
     const size_t desc_words = descs_.size() * sizeof(TreeDesc) / 4;
     if ((rc = reserve(desc_words + 4, &d_off)) != AIC_OK) return rc;
     std::memcpy(at(d_off), descs_.data(), descs_.size() * sizeof(TreeDesc));
-    const size_t job_words = jobs_.size() * sizeof(ApplyJob) / 4;
+    const size_t job_words = (jobs_.size() + 1) * sizeof(ApplyJob) / 4;      // + the query-section job of the zero-copy path
     if ((rc = reserve(job_words + 4, &j_off)) != AIC_OK) return rc;
     std::memcpy(at(j_off), jobs_.data(), jobs_.size() * sizeof(ApplyJob));
 
@@ -531,35 +549,82 @@ class Mirror {
       dscr_cap_ = scr_bytes * 2;
       AIC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dscr_), dscr_cap_));
     }
-    if (out_words * 4 > pin_out_cap_) {
+    if ((out_words + 16) * 4 > pin_out_cap_) {
       if (pin_out_) AIC_HIP_TRY(hipHostFree(pin_out_));
-      pin_out_cap_ = out_words * 8;
+      pin_out_cap_ = (out_words + 16) * 8;
       AIC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pin_out_), pin_out_cap_, hipHostMallocDefault));
+      std::memset(pin_out_, 0, pin_out_cap_);
     }
     if (!ev0_) {
       AIC_HIP_TRY(hipEventCreate(&ev0_));
       AIC_HIP_TRY(hipEventCreate(&ev1_));
     }
-
-    AIC_HIP_TRY(hipMemcpyAsync(dblob_, pinned_, blob_bytes, hipMemcpyHostToDevice, stream));
+    if (!done_counter_) {
+      AIC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&done_counter_), 64));
+      AIC_HIP_TRY(hipMemset(done_counter_, 0, 64));
+    }
+    // ZERO-COPY round trip (default; AIC_SUFFIX_STAGED=1 restores the two staging copies + stream synchronisation): pinned
+    // host memory is mapped into the device's address space, so
+    //   * the apply kernel reads its job list and the delta records straight from the pinned blob, and one more job brings
+    //     the query section (patterns, queries, tree descriptors — read by thousands of waves) into device memory;
+    //   * the select kernel writes the winners straight into the pinned result block and its last workgroup raises a flag
+    //     there, which this thread polls.
+    // That takes two copy commands, their dependency barriers and the stream synchronisation's wake-up out of a round trip the
+    // engine waits for on every step (0.21 ms per step at B = 64, half of it device-side: tools/host_profile.py).
+    static const bool staged = [] {
+      const char* e = std::getenv("AIC_SUFFIX_STAGED");
+      return e && e[0] == '1';
+    }();
+    const int32_t* blob_dev = dblob_;          // where the kernels read the blob from
+    int32_t* pin_out_dev = nullptr;
+    // a large blob (whole trees: the first step after prompts were cached, hundreds of megabytes) goes by the copy engine
+    const bool blob_direct = !staged && blob_bytes <= (static_cast<size_t>(4) << 20);
+    if (!staged) {
+      void* p = nullptr;
+      AIC_HIP_TRY(hipHostGetDevicePointer(&p, pin_out_, 0));
+      pin_out_dev = static_cast<int32_t*>(p);
+    }
+    if (blob_direct) {
+      void* p = nullptr;
+      AIC_HIP_TRY(hipHostGetDevicePointer(&p, pinned_, 0));
+      blob_dev = static_cast<const int32_t*>(p);
+      // the query section [p_off, j_off) -> the same offsets of the device blob (one contiguous job)
+      ApplyJob q;
+      q.dst = dblob_ + p_off;
+      q.src_off = p_off;
+      q.idx_off = -1;
+      q.dst_first = 0;
+      q.n = static_cast<int32_t>(j_off - p_off);
+      q.rec_words = 1;
+      q.pad = 0;
+      jobs_.push_back(q);
+      max_job_words_ = std::max<int64_t>(max_job_words_, q.n);
+      // the job list was already written behind the descriptors: re-write it with the extra job (room was reserved)
+      std::memcpy(at(j_off), jobs_.data(), jobs_.size() * sizeof(ApplyJob));
+    } else {
+      AIC_HIP_TRY(hipMemcpyAsync(dblob_, pinned_, blob_bytes, hipMemcpyHostToDevice, stream));
+    }
     mirrored_bytes_ = static_cast<int64_t>(blob_bytes);
     if (!jobs_.empty()) {
       const int bx = static_cast<int>(std::min<int64_t>(std::max<int64_t>(max_job_words_ / 1024, 1), 256));
       dim3 grid(bx, static_cast<unsigned>(jobs_.size()));
       hipLaunchKernelGGL(mirror_apply_kernel, grid, dim3(256), 0, stream,
-                         reinterpret_cast<const ApplyJob*>(dblob_ + j_off), dblob_);
+                         reinterpret_cast<const ApplyJob*>(blob_dev + j_off), blob_dev);
       if ((rc = launch_status("mirror_apply_kernel")) != AIC_OK) return rc;
     }
     float* scr_score = reinterpret_cast<float*>(dscr_);
     int32_t* scr_n = dscr_ + n_items;
     int32_t* scr_tok = dscr_ + 2 * n_items;
     float* scr_prob = reinterpret_cast<float*>(dscr_ + 2 * n_items + n_items * cap);
-    int32_t* d_out = dscr_ + scr_words;
+    int32_t* d_out = staged ? dscr_ + scr_words : pin_out_dev;
     int32_t* o_n = d_out;
     float* o_score = reinterpret_cast<float*>(d_out + nq);
     int32_t* o_match = d_out + 2 * nq;
     int32_t* o_tok = d_out + 3 * nq;
     float* o_prob = reinterpret_cast<float*>(d_out + 3 * nq + static_cast<size_t>(nq) * cap);
+    int32_t* flag_host = pin_out_ + pin_out_cap_ / 4 - 16;       // last 64 bytes of the result block
+    int32_t* flag_dev = staged ? nullptr : pin_out_dev + pin_out_cap_ / 4 - 16;
+    epoch_ = epoch_ == 0x7ffffff0 ? 1 : epoch_ + 1;
 
     AIC_HIP_TRY(hipEventRecord(ev0_, stream));
     const int waves_per_block = 4;
@@ -571,13 +636,35 @@ class Mirror {
     if ((rc = launch_status("suffix_match_kernel")) != AIC_OK) return rc;
     hipLaunchKernelGGL(suffix_select_kernel, dim3(nq), dim3(64), 0, stream,
                        reinterpret_cast<const QueryRec*>(dblob_ + q_off), n_starts, cap, scr_score, scr_n,
-                       scr_tok, scr_prob, o_n, o_score, o_match, o_tok, o_prob);
+                       scr_tok, scr_prob, o_n, o_score, o_match, o_tok, o_prob, done_counter_, flag_dev, epoch_);
     if ((rc = launch_status("suffix_select_kernel")) != AIC_OK) return rc;
     AIC_HIP_TRY(hipEventRecord(ev1_, stream));
-    AIC_HIP_TRY(hipMemcpyAsync(pin_out_, d_out, out_words * 4, hipMemcpyDeviceToHost, stream));
-    AIC_HIP_TRY(hipStreamSynchronize(stream));
-    float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) match_us_ = ms * 1000.0f;
+    if (staged) {
+      AIC_HIP_TRY(hipMemcpyAsync(pin_out_, d_out, out_words * 4, hipMemcpyDeviceToHost, stream));
+      AIC_HIP_TRY(hipStreamSynchronize(stream));
+      float ms = 0.0f;
+      if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) match_us_ = ms * 1000.0f;
+    } else {
+      // poll the flag; a launch this size takes tens of microseconds — after 50 ms something else is wrong and the stream
+      // is asked instead (an error there is reported; a completed stream without the flag is one too)
+      timing_pending_ = true;
+      const auto t0 = std::chrono::steady_clock::now();
+      bool seen = false;
+      for (uint32_t spin = 0;; ++spin) {
+        if (__atomic_load_n(flag_host, __ATOMIC_ACQUIRE) == epoch_) {
+          seen = true;
+          break;
+        }
+        __builtin_ia32_pause();
+        if ((spin & 1023) == 1023 &&
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 50.0)
+          break;
+      }
+      if (!seen) {
+        AIC_HIP_TRY(hipStreamSynchronize(stream));
+        AIC_REQUIRE(__atomic_load_n(flag_host, __ATOMIC_ACQUIRE) == epoch_, "suffix select launch finished without raising its flag");
+      }
+    }
 
     const int32_t* h_n = pin_out_;
     const float* h_score = reinterpret_cast<const float*>(pin_out_ + nq);
@@ -596,7 +683,14 @@ class Mirror {
     return AIC_OK;
   }
 
-  float match_us() const { return match_us_; }
+  float match_us() {
+    if (timing_pending_) {         // the zero-copy path does not wait for the events inside the call
+      float ms = 0.0f;
+      if (hipEventSynchronize(ev1_) == hipSuccess && hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) match_us_ = ms * 1000.0f;
+      timing_pending_ = false;
+    }
+    return match_us_;
+  }
   int64_t mirrored_bytes() const { return mirrored_bytes_; }
 
  private:
@@ -614,6 +708,9 @@ class Mirror {
   int32_t* pin_out_ = nullptr;
   size_t pin_out_cap_ = 0;
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+  int32_t* done_counter_ = nullptr;   // device: workgroups of the select launch that have finished
+  int32_t epoch_ = 0;                 // value the flag (last word of pin_out_) takes when the current call's results are in
+  bool timing_pending_ = false;
   float match_us_ = 0.0f;
   int64_t mirrored_bytes_ = 0;
 };
@@ -1014,7 +1111,7 @@ int aic_sc_last_timing(const aic_suffix_cache* c, float* build_us, float* device
 
 int aic_sc_last_stats(const aic_suffix_cache* c, float* match_us, int64_t* mirrored_bytes, int64_t* n_nodes_total) {
   AIC_REQUIRE(c, "null cache");
-  if (match_us) *match_us = c->mirror.match_us();
+  if (match_us) *match_us = const_cast<aic_suffix_cache*>(c)->mirror.match_us();
   if (mirrored_bytes) *mirrored_bytes = c->mirror.mirrored_bytes();
   if (n_nodes_total) {
     int64_t n = static_cast<int64_t>(c->global->host.num_nodes());

@@ -71,17 +71,20 @@ def _runner(level, full):
 
 
 def _drive(r, capture_hidden):
-    """20 requests decode (SP steps: 20 tokens > threshold), then 14 finish and 6 decode on (shift steps)."""
+    """32 requests decode (SP steps: 32 tokens > threshold), then 24 finish and 8 decode on (shift steps).  The batches
+    fill their graph sizes exactly: with mirror ranks a padded token row of THIS rank stands in for a real row of a peer
+    (row 16 + t of the attention output is "rank 1's heads of token t"), and padded rows hold whatever the allocator left
+    there — real peers would hand over real rows."""
     from arcticinference_amd.workload import TokenSource
     src = TokenSource(vocab_size=2000, seed=12, n_motifs=3, motif_min=8, motif_max=16, p_motif=0.9)
     sched = H.MiniScheduler(16, 400)
-    for i in range(20):
-        sched.add(f"r{i}", [int(x) for x in src.stream(24 + i % 5, i)])
+    for i in range(32):
+        sched.add(f"r{i}", [int(x) for x in src.stream(24 + i % 4, i)])     # 816 prompt tokens: even, no padded row under SP = 2
     hs, toks, sizes = [], [], []
     from vllm import forward_context
     for step in range(12):
         if step == 6:
-            for i in range(6, 20):
+            for i in range(8, 32):
                 sched.finish(f"r{i}")
         h0 = len(forward_context.history)
         out = r.execute_model(sched.schedule())
@@ -144,7 +147,7 @@ def test_sp_and_shift_graphs_are_captured_and_replayed_equal_to_eager(stub_vllm,
         replays0 = cuda_graphs.stats["replayed"]
         got_toks, got_hs, got_sizes = _drive(r, lambda: hook.hidden)
         assert got_toks == want_toks and got_sizes == want_sizes
-        # steps 1-5: 20 decode tokens > threshold -> Ulysses graphs (16 tokens per rank); 6-11: 6 tokens -> shift graph (8)
+        # steps 1-5: 32 decode tokens > threshold -> Ulysses graphs (16 tokens per rank); 6-11: 8 tokens -> shift graph (8)
         assert got_sizes[1:6] == [32] * 5 and got_sizes[6:] == [8] * 6, got_sizes
         assert cuda_graphs.stats["replayed"] - replays0 == 11
         for i, (a, b) in enumerate(zip(want_hs, got_hs)):
