@@ -452,7 +452,7 @@ skinny_gemm_kernel(const uint4* __restrict__ W, const uint4* __restrict__ X, int
 // projection — alone a 30 us launch at 4.4 TB/s, a third of it ramp and tail — rides inside the 0.5-1 GB head launch.
 // Workgroups [0, gate_bx * gate_by) run the gate body (split-K partials), the rest the head body (arg-max epilogue;
 // fp8 head: activations quantised on the way into LDS).
-template <bool FP8H, int MT>
+template <bool FP8H, int MT, bool XQ>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 skinny_pair_kernel(GemmArgs G, GemmArgs Hd, int gate_bx, int gate_by) {
   __shared__ uint4 lds[2][kChunkSteps * MT * 64];
@@ -460,7 +460,7 @@ skinny_pair_kernel(GemmArgs G, GemmArgs Hd, int gate_bx, int gate_by) {
   if (b < n_gate)
     skinny_gemm_body<false, MT, 0, false>(G, lds, b % gate_bx, b / gate_bx);
   else
-    skinny_gemm_body<FP8H, MT, 1, FP8H>(Hd, lds, b - n_gate, 0);
+    skinny_gemm_body<FP8H, MT, 1, XQ>(Hd, lds, b - n_gate, 0);
 }
 
 // the head alone with on-the-fly activation quantisation (last draft head of the fused path)
@@ -1142,6 +1142,8 @@ int aic_lstm_head(aic_lstm* m, int head_index, const int32_t* last_tokens, int b
   return run_head(m, head_index, s, out_tokens, 1, 0, out_vals);
 }
 
+static std::atomic<int> g_lstm_xq{0};
+
 // The whole k-head draft of the LSTM speculator in 3 k + 3 launches (12 at k = 3; the head-by-head form takes 5-6 per
 // head + 1): the gate projection of head h + 1 shares a launch with the LM head of head h (skinny_pair_kernel), the arg-max
 // over the LM head's partials is finished inside the next cell launch (or once at the end), and the fp8 head quantises its
@@ -1160,10 +1162,17 @@ static int propose_fused(aic_lstm* m, int k, int64_t* out_tokens, float* out_val
     return GemmArgs{first ? m->proj0_t : m->proj1_t, first ? m->x0 : m->h_bf16, m->gate_rowtiles, steps_total,
                     steps_total / splits, m->part, 4 * Ds, nullptr, 1.0f, 0, 0, nullptr, nullptr, nullptr};
   };
+  // (XQ — the fp8 head quantising its activations on the way into LDS — is built and bit-identical, but measured slower
+  // than the 5 us quant_act launch it removes: head alone 98.1 against 89.5 us at 32 rows, rocprofv3
+  // profiles/r03_lstm_kernel_stats.csv; the 2004 workgroups each redo the conversion of the whole activation matrix.)
+  const bool xq = fp8 && g_lstm_xq.load() != 0;
   auto head_args = [&](int head) {
-    if (fp8)
+    if (fp8 && xq)
       return GemmArgs{m->head8_t, m->h_bf16, m->head_rowtiles, Ds / 64, Ds / 64, nullptr, 0, nullptr, m->head8_scale,
                       c.vocab_size, c.vocab_offset, m->best_val, m->best_idx, m->amax + head};
+    if (fp8)
+      return GemmArgs{m->head8_t, m->h_fp8, m->head_rowtiles, Ds / 64, Ds / 64, nullptr, 0, m->x_scale, m->head8_scale,
+                      c.vocab_size, c.vocab_offset, m->best_val, m->best_idx, nullptr};
     return GemmArgs{m->head_t, m->h_bf16, m->head_rowtiles, Ds / 32, Ds / 32, nullptr, 0, nullptr, 1.0f, c.vocab_size,
                     c.vocab_offset, m->best_val, m->best_idx, nullptr};
   };
@@ -1186,26 +1195,37 @@ static int propose_fused(aic_lstm* m, int k, int64_t* out_tokens, float* out_val
                        static_cast<const uint16_t*>(m->w.state_ln_w), static_cast<const uint16_t*>(m->w.state_ln_b),
                        static_cast<const uint16_t*>(m->cell), m->ss2_part, mt, m->h_bf16, m->amax + h);
     if ((rc = launch_status("lstm_cell_kernel")) != AIC_OK) return rc;
+    if (fp8 && !xq) {
+      hipLaunchKernelGGL(quant_act_kernel, dim3(64), dim3(256), 0, s, m->h_bf16, m->h_fp8, m->amax + h, m->x_scale, Ds, mt);
+      if ((rc = launch_status("quant_act_kernel")) != AIC_OK) return rc;
+    }
     const GemmArgs Hd = head_args(h);
     if (h + 1 < k) {
       const GemmArgs G = gate_args(h + 1, &splits);
       const int gate_bx = (m->gate_rowtiles + 3) / 4;
       const dim3 grid(static_cast<unsigned>(gate_bx * splits + m->head_blocks));
-#define AIC_PAIR(FP8H_, MT_) \
-  hipLaunchKernelGGL((skinny_pair_kernel<FP8H_, MT_>), grid, dim3(256), 0, s, G, Hd, gate_bx, splits)
-      if (fp8) {
-        if (mt == 1) AIC_PAIR(true, 1); else AIC_PAIR(true, 2);
+#define AIC_PAIR(FP8H_, MT_, XQ_) \
+  hipLaunchKernelGGL((skinny_pair_kernel<FP8H_, MT_, XQ_>), grid, dim3(256), 0, s, G, Hd, gate_bx, splits)
+      if (fp8 && xq) {
+        if (mt == 1) AIC_PAIR(true, 1, true); else AIC_PAIR(true, 2, true);
+      } else if (fp8) {
+        if (mt == 1) AIC_PAIR(true, 1, false); else AIC_PAIR(true, 2, false);
       } else {
-        if (mt == 1) AIC_PAIR(false, 1); else if (mt == 2) AIC_PAIR(false, 2); else AIC_PAIR(false, 4);
+        if (mt == 1) AIC_PAIR(false, 1, false); else if (mt == 2) AIC_PAIR(false, 2, false); else AIC_PAIR(false, 4, false);
       }
 #undef AIC_PAIR
       if ((rc = launch_status("skinny_pair_kernel")) != AIC_OK) return rc;
-    } else if (fp8) {
+    } else if (fp8 && xq) {
       if (mt == 1)
         hipLaunchKernelGGL((skinny_head_xq_kernel<1>), dim3(m->head_blocks), dim3(256), 0, s, Hd);
       else
         hipLaunchKernelGGL((skinny_head_xq_kernel<2>), dim3(m->head_blocks), dim3(256), 0, s, Hd);
       if ((rc = launch_status("skinny_head_xq_kernel")) != AIC_OK) return rc;
+    } else if (fp8) {
+      rc = launch_gemm<true, 1>(mt, dim3(m->head_blocks, 1), s, Hd.W, Hd.X, Hd.n_rowtiles, Hd.steps_total,
+                                Hd.steps_per_split, nullptr, 0, m->x_scale, m->head8_scale, Hd.n_valid_rows, Hd.row_offset,
+                                Hd.best_val, Hd.best_idx);
+      if (rc != AIC_OK) return rc;
     } else {
       rc = launch_gemm<false, 1>(mt, dim3(m->head_blocks, 1), s, Hd.W, Hd.X, Hd.n_rowtiles, Hd.steps_total,
                                  Hd.steps_per_split, nullptr, 0, nullptr, 1.0f, Hd.n_valid_rows, Hd.row_offset,
@@ -1219,8 +1239,9 @@ static int propose_fused(aic_lstm* m, int k, int64_t* out_tokens, float* out_val
 }
 
 static std::atomic<int> g_lstm_fused{1};
-int aic_debug_lstm_fused(int on) {
+int aic_debug_lstm_fused(int on) {     // 0 head by head, 1 fused (default), 2 fused + on-the-fly fp8 activation quantisation
   g_lstm_fused.store(on);
+  g_lstm_xq.store(on == 2 ? 1 : 0);
   return AIC_OK;
 }
 

@@ -312,8 +312,9 @@ int aic_lstm_padding_size(int batch);
 int aic_lstm_propose(aic_lstm* m, const void* hidden, const int32_t* hidden_index, const int32_t* last_tokens,
                      int batch, int num_predict_tokens, int64_t* out_tokens, float* out_vals, void* stream);
 /* debug aid: 1 (default) the whole-draft entry point of an LSTM speculator runs the fused schedule (LM head of head h and
- * gate projection of head h + 1 in one launch, arg-max finished inside the next cell launch, fp8 activations quantised on
- * the way into LDS: 3 k + 3 launches), 0 the head-by-head one (5-6 launches per head); both compute the same tokens. */
+ * gate projection of head h + 1 in one launch, arg-max finished inside the next cell launch: 4 k + 3 launches with an fp8
+ * head, 3 k + 3 with a bf16 one), 0 the head-by-head one (5-6 launches per head), 2 the fused one with the fp8 head
+ * quantising its activations on the way into LDS (no quant launch; measured slower); all compute the same tokens. */
 int aic_debug_lstm_fused(int on);
 /* single-head entry points for the vocab-parallel (TP/SP > 1) loop, where an all-gather of
  * (value, index) sits between heads.  State lives in the handle. */

@@ -17,4 +17,5 @@ def get_model(*, vllm_config):
         set_current_vllm_config(prev)
     loaded.append((arch, get_tp_group().world_size))
     from vllm.compilation import cuda_graphs
-    return cuda_graphs.install(model, vllm_config)
+    # (draft models of the plugin are not nn.Modules with a forward: nothing to wrap)
+    return cuda_graphs.install(model, vllm_config) if hasattr(model, "forward") else model

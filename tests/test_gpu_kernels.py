@@ -816,9 +816,9 @@ def test_lstm_speculator_small(B, fp8):
                                            (64, True, 512, 768, 3000), (13, True, 1024, 512, 50000), (40, False, 1024, 1024, 50000)])
 def test_lstm_fused_schedule_equals_head_by_head(B, fp8, Ds, H, V):
     """The whole-draft entry point's fused schedule (LM head of head h + gate projection of head h + 1 in one launch, the
-    arg-max finished inside the next cell launch, fp8 activations quantised on the way into LDS: 12 launches at k = 3) and the
-    head-by-head one (16-19) are the same arithmetic operation by operation: tokens AND bf16-rounded maximum logits are
-    bit-identical, with and without the hidden-state row index."""
+    arg-max finished inside the next cell launch: 12-15 launches at k = 3) and the head-by-head one (16-19) are the same
+    arithmetic operation by operation: tokens AND bf16-rounded maximum logits are bit-identical, with and without the
+    hidden-state row index."""
     import ctypes
     from arcticinference_amd import _native as N
     from arcticinference_amd.speculator import ArcticLSTMSpeculator, LSTMSpeculatorConfig, random_lstm_weights
@@ -844,9 +844,10 @@ def test_lstm_fused_schedule_equals_head_by_head(B, fp8, Ds, H, V):
     try:
         for index in (None, hidx):
             t0, v0 = run(0, index)
-            t1, v1 = run(1, index)
-            assert torch.equal(t0, t1) and torch.equal(v0, v1), (B, fp8, index is not None)
-            assert (t1 >= 0).all() and (t1 < V).all() and not torch.isnan(v1).any()
+            for mode in (1, 2):        # 2: the fp8 head quantises its activations on the way into LDS (built, not the default)
+                t1, v1 = run(mode, index)
+                assert torch.equal(t0, t1) and torch.equal(v0, v1), (B, fp8, mode, index is not None)
+            assert (t0 >= 0).all() and (t0 < V).all() and not torch.isnan(v0).any()
     finally:
         lib.aic_debug_lstm_fused(1)
 

@@ -187,10 +187,10 @@ def lstm(B, fp8=True):
     ids = torch.randint(0, 128256, (B,), device=dev)
     head_gb = 128256 * 4096 * (1 if (fp8 and B <= 32) else 2) / 1e9
     gate_gb = 4 * 4096 * 4096 * 2 / 1e9
-    for fused in (0, 1):          # head-by-head schedule against the fused one (aic_debug_lstm_fused)
+    for fused in (0, 1, 2):       # head-by-head schedule, the fused one, fused + on-the-fly fp8 activations (aic_debug_lstm_fused)
         N.lib().aic_debug_lstm_fused(fused)
         us = timeit(lambda: m.generate_proposals(ids, hid, 3), iters=10)
-        print(f"lstm B={B} fp8={fp8 and B <= 32} {'fused' if fused else 'head-by-head'}: {us:8.1f} us per 3-head propose; "
+        print(f"lstm B={B} fp8={fp8 and B <= 32} {('head-by-head', 'fused', 'fused+xq')[fused]}: {us:8.1f} us per 3-head propose; "
               f"weights {3 * (head_gb + gate_gb):.2f} GB -> {3 * (head_gb + gate_gb) / us * 1e6 / 1e3:5.2f} TB/s "
               f"({3 * (head_gb + gate_gb) / us * 1e6 / 1e3 / 8:.2f} of 8 TB/s)")
     N.lib().aic_debug_lstm_fused(1)
