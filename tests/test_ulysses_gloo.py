@@ -1,4 +1,4 @@
-"""CPU, world_size 2 and 4 over gloo: the N>1 path of UlyssesAttention (pack -> all-to-all -> attention on
+"""CPU, world_size 2, 4 and 8 over gloo: the N>1 path of UlyssesAttention (pack -> all-to-all -> attention on
 local heads over ALL tokens -> all-to-all -> unpack) reproduces single-process attention over all heads.
 The HIP pack/unpack kernels cannot run here, so the test injects the oracle's torch expressions of
 ulysses.py:493-517 for those two copies; group logic, buffer shapes, strided q/k/v views and the
@@ -77,7 +77,7 @@ def _full(q, k, v, Hq, Hkv, D, N):
     return (torch.softmax(s, -1) @ V).transpose(0, 1).reshape(N, Hq * D)
 
 
-@pytest.mark.parametrize("world,Hq,Hkv", [(2, 8, 2), (4, 8, 4)])
+@pytest.mark.parametrize("world,Hq,Hkv", [(2, 8, 2), (4, 8, 4), (8, 32, 8)])     # (8, 32, 8): Llama-3.1-8B heads at SP = 8, one kv head per rank
 def test_ulysses_attention_gloo(world, Hq, Hkv):
     ctx = mp.get_context("spawn")
     qout = ctx.Queue()

@@ -12,20 +12,23 @@ timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1
 tail -2 $O/pytest_gpu.txt
 timeout -k 10 600 python bench.py 2> $O/bench.err | grep '^{' > $O/bench.json
 cut -c1-300 $O/bench.json
-timeout -k 10 600 python bench.py --lanes 1 --no-cpu-baseline 2>> $O/bench.err | grep '^{' > $O/bench_1lane.json
+timeout -k 10 600 python bench.py --lanes 1 --no-cpu-baseline --no-replay-check 2>> $O/bench.err | grep '^{' > $O/bench_1lane.json
 cut -c1-300 $O/bench_1lane.json
-timeout -k 10 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>> $O/bench.err | grep '^{' > $O/bench_20steps.json
-timeout -k 10 600 python bench.py --kv-dtype fp8 --no-cpu-baseline 2>> $O/bench.err | grep '^{' > $O/bench_fp8kv.json
+timeout -k 10 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-replay-check 2>> $O/bench.err | grep '^{' > $O/bench_20steps.json
+timeout -k 10 600 python bench.py --kv-dtype fp8 --no-cpu-baseline --no-replay-check 2>> $O/bench.err | grep '^{' > $O/bench_fp8kv.json
+# BASELINE configs[1]: the LSTM speculator alone (draft model every step), and the headline under the reference's indexing
+timeout -k 10 600 python bench.py --no-suffix --no-cpu-baseline --no-replay-check 2>> $O/bench.err | grep '^{' > $O/bench_nosuffix.json
+timeout -k 10 600 python bench.py --proposal-indexing reference --no-cpu-baseline --no-replay-check 2>> $O/bench.err | grep '^{' > $O/bench_reference_indexing.json
 timeout -k 10 600 python tools/microbench.py attn fp8 mix mid ql lstm rej > $O/microbench.txt 2>&1
 bash tools/ab_sp.sh > $O/rehearsal_sp.txt 2>&1 || true
 echo microbench done
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $O/stats -o p -- python3 $R/bench.py --no-cpu-baseline > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $O/stats -o p -- python3 $R/bench.py --no-cpu-baseline --no-replay-check > $O/stats.log 2>&1
 echo stats done
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-replay-check > $O/pmc_fetch.log 2>&1
 grep '^{' $O/pmc_fetch.log > $O/pmc_bench.json || true
 echo fetch pass done
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-replay-check > $O/pmc_write.log 2>&1
 echo write pass done
 cd $R
 DB=$(find $O/stats -name '*.db' | head -1)
