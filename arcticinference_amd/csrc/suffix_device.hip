@@ -563,17 +563,19 @@ class Mirror {
       AIC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&done_counter_), 64));
       AIC_HIP_TRY(hipMemset(done_counter_, 0, 64));
     }
-    // ZERO-COPY round trip (default; AIC_SUFFIX_STAGED=1 restores the two staging copies + stream synchronisation): pinned
-    // host memory is mapped into the device's address space, so
+    // ZERO-COPY round trip, built and measured in r03, NOT the default (AIC_SUFFIX_ZEROCOPY=1 selects it): pinned host memory is
+    // mapped into the device's address space, so
     //   * the apply kernel reads its job list and the delta records straight from the pinned blob, and one more job brings
     //     the query section (patterns, queries, tree descriptors — read by thousands of waves) into device memory;
     //   * the select kernel writes the winners straight into the pinned result block and its last workgroup raises a flag
     //     there, which this thread polls.
-    // That takes two copy commands, their dependency barriers and the stream synchronisation's wake-up out of a round trip the
-    // engine waits for on every step (0.21 ms per step at B = 64, half of it device-side: tools/host_profile.py).
+    // It takes two copy commands, their dependency barriers and the stream synchronisation out of the round trip — and gives
+    // the time back inside the kernels, which now wait on the host link: rocprofv3 on the bench (profiles/r03_kernel_stats.csv
+    // against r02's): mirror_apply 17.7 -> 30.1 us, suffix_select 5.4 -> 13.7 us per launch; the round trip as the host sees it
+    // 0.21 -> 0.22 ms per lane step on one GPU, 0.194 -> 0.204 ms at rehearsed SP = 8 (same-box A/B).  The staged form stays.
     static const bool staged = [] {
-      const char* e = std::getenv("AIC_SUFFIX_STAGED");
-      return e && e[0] == '1';
+      const char* e = std::getenv("AIC_SUFFIX_ZEROCOPY");
+      return !(e && e[0] == '1');
     }();
     const int32_t* blob_dev = dblob_;          // where the kernels read the blob from
     int32_t* pin_out_dev = nullptr;

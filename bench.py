@@ -555,7 +555,7 @@ def main():
         traffic = traffic_source = None
         default_shape = (world == 1 and args.rehearse_sp <= 1 and args.kv_dtype == "auto" and B == 64 and PL == 4096
                          and GL == 256 and shape.num_layers == 32 and not args.no_lstm)
-        for name in ("r02_pmc_attention.json", "r01_pmc_attention.json"):
+        for name in ("r03_pmc_attention.json", "r02_pmc_attention.json", "r01_pmc_attention.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if default_shape and os.path.exists(pmc):
                 try:
