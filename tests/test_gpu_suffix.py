@@ -202,3 +202,24 @@ def test_simulator_path_mode_matches_oracle_driver():
     b = pd.DataFrame(S.run_task(OracleSuffixCache, data, None, **cfg)).drop(columns=["spec_ms", "update_ms"])
     assert a["num_accept_toks"].sum() > 0
     pd.testing.assert_frame_equal(a, b)
+
+
+def test_zero_copy_round_trip_gives_the_golden_digests():
+    """The alternative round trip (AIC_SUFFIX_ZEROCOPY=1: the apply kernel reads the deltas from pinned host memory, the
+    select kernel writes the winners there and raises a flag the host polls; measured, not the default) against the same
+    reference-generated digests.  The switch is read once per process: run in a child."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "import golden_utils as gu, test_gpu_suffix as T\n"
+            "from arcticinference_amd.suffix_cache import SuffixCache\n"
+            "want = gu.load('suffix_replay.json')[0]\n"
+            "got = T._replay(SuffixCache(64), want['config'], batched=False)\n"
+            "assert got == want['per_request'], 'digests differ'\n"
+            "got = T._replay(SuffixCache(64), want['config'], batched=True)\n"
+            "print('ok')\n") % (os.path.join(root, "tests"), root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, AIC_SUFFIX_ZEROCOPY="1"))
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
