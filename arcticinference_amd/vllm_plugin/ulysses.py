@@ -59,6 +59,10 @@ def build_ulysses_patches():
     from .custom_ops import attention_op
     from .model_runner import is_shift_parallel_mode
 
+    # registered NOW, while the patches are built (eagerly, once per process): the first forward of a model may already
+    # run under Dynamo, where creating a custom op is not something the tracer can do
+    arctic_attention = attention_op()
+
     # -----------------------------------------------------------------------------------------------
     class UlyssesModelConfigPatch(ArcticPatch[ModelConfig]):
         _orig_get_num_kv_heads = ModelConfig.get_num_kv_heads
@@ -324,7 +328,7 @@ def build_ulysses_patches():
             are not served by the route and keep the direct call."""
             if kwargs or not getattr(self, "layer_name", None):
                 return self._arctic_forward(query, key, value, **kwargs)
-            return attention_op()(query, key, value, self.layer_name)
+            return arctic_attention(query, key, value, self.layer_name)
 
         def _arctic_forward(self, query, key, value, **kwargs):
             """The eager body behind the op: head repartition around attention (ulysses.py:457-519) + the verify route."""
