@@ -45,6 +45,12 @@ class MlpWeights(ctypes.Structure):
                 ("ln_b", c_void_p * 8), ("head", c_void_p * 8)]
 
 
+class MlpStack(ctypes.Structure):
+    _fields_ = [("n_emb", c_int32), ("n_proj", c_int32), ("n_ln", c_int32), ("pad", c_int32)] + [
+        (name, (c_void_p * 3) * 8) for name in ("emb_ln_w", "emb_ln_b", "emb_lin", "proj_ln_w", "proj_ln_b", "proj_lin",
+                                                 "ln_lin", "ln_ln_w", "ln_ln_b")]
+
+
 def build(force: bool = False) -> str:
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     if force:
@@ -110,6 +116,7 @@ _SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p]),
     "aic_lstm_create": (c_int, [POINTER(LstmConfig), POINTER(LstmWeights), POINTER(c_void_p)]),
     "aic_mlp_create": (c_int, [POINTER(LstmConfig), POINTER(MlpWeights), POINTER(c_void_p)]),
+    "aic_mlp_create_stacked": (c_int, [POINTER(LstmConfig), POINTER(MlpWeights), POINTER(MlpStack), POINTER(c_void_p)]),
     "aic_mlp_set_embedding_rows": (c_int, [c_void_p, c_void_p]),
     "aic_lstm_destroy": (None, [c_void_p]),
     "aic_quantize_fp8_per_tensor": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

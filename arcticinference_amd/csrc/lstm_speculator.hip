@@ -686,6 +686,77 @@ mlp_cell_kernel(const float* __restrict__ part, int n_splits, int m_pad, int bat
   if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(amax));
 }
 
+// ---- stacked "sum_rnn" stages (ArcticLSTMSpeculator with multi-entry dimension lists, arctic_speculator.py:478-542):
+// emb / proj are nn.Sequentials [base, (LayerNorm, GELU, Linear)*], ln is [LayerNorm, (GELU, Linear, LayerNorm)*].  One
+// generic row kernel covers every elementwise piece between two Linears:
+//     x = A  [+ alpha * B]   ->   [LayerNorm(w, b)]   ->   [GELU]   ->   fragment-major bf16 for the next GEMM
+// where A / B are either split-K partials of a Linear (summed in fp32 and rounded: the Linear's bf16 output) or bf16 rows
+// (an embedding table gathered by token, or rows looked up by the caller).  Every op rounds to bf16 like the reference.
+struct StageSrc {
+  const float* part;        // [n_splits][m_pad][Ds] or nullptr
+  int n_splits;
+  const uint16_t* rows;     // bf16 [*, Ds]: row `token` (by_token) or row m
+  int by_token;
+};
+__device__ __forceinline__ float stage_value(const StageSrc& a, int m, int tok, int m_pad, int Ds, int j) {
+  if (a.part != nullptr) {
+    float s = 0.0f;
+    for (int sp = 0; sp < a.n_splits; ++sp) s += a.part[(static_cast<int64_t>(sp) * m_pad + m) * Ds + j];
+    return r(s);
+  }
+  return bf16_to_f32(a.rows[static_cast<int64_t>(a.by_token ? tok : m) * Ds + j]);
+}
+__global__ void __launch_bounds__(1024)
+stage_kernel(StageSrc a, StageSrc b, int has_b, float alpha, const int32_t* __restrict__ tokens, int m_pad, int batch,
+             const uint16_t* __restrict__ ln_w, const uint16_t* __restrict__ ln_b, int do_ln, int do_gelu, int Ds, int MT,
+             uint4* __restrict__ out_frag, unsigned int* __restrict__ amax_bits) {
+  extern __shared__ float smem[];  // [Ds]
+  __shared__ float sh[16];
+  const int m = blockIdx.x;
+  if (m >= batch) {
+    for (int k8 = threadIdx.x; k8 < Ds / 8; k8 += blockDim.x) out_frag[xunit_bf16(m, k8, MT)] = make_uint4(0, 0, 0, 0);
+    return;
+  }
+  int tok = tokens ? tokens[m] : 0;
+  if (tok < 0) tok = 0;
+  float ss = 0.0f;
+  for (int j = threadIdx.x; j < Ds; j += blockDim.x) {
+    float x = stage_value(a, m, tok, m_pad, Ds, j);
+    if (has_b) x = r(fmaf(alpha, stage_value(b, m, tok, m_pad, Ds, j), x));   // states.add_(z, alpha=...)
+    smem[j] = x;
+    ss += r(x * x);
+  }
+  float rs = 1.0f;
+  if (do_ln) {
+    ss = block_sum(ss, sh);
+    rs = r(rsqrtf(r(r(ss / static_cast<float>(Ds)) + 1e-6f)));
+  } else {
+    __syncthreads();
+  }
+  float amax = 0.0f;
+  for (int k8 = threadIdx.x; k8 < Ds / 8; k8 += blockDim.x) {
+    uint16_t h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int j = k8 * 8 + e;
+      float y = smem[j];
+      if (do_ln) {
+        y = r(y * rs);
+        y = r(bf16_to_f32(ln_w[j]) * y);
+        y = r(y + bf16_to_f32(ln_b[j]));
+      }
+      if (do_gelu) y = r(gelu_erf(y));
+      h[e] = f32_to_bf16(y);
+      amax = fmaxf(amax, fabsf(y));
+    }
+    out_frag[xunit_bf16(m, k8, MT)] = *reinterpret_cast<uint4*>(h);
+  }
+  if (amax_bits) {
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(amax));
+  }
+}
+
 // ---- dynamic per-tensor activation quantisation for the fp8 LM head (fp8.py:303-308) ------------
 __global__ void __launch_bounds__(256)
 quant_act_kernel(const uint4* __restrict__ h_bf16, uint4* __restrict__ h_fp8, const unsigned int* __restrict__ amax_bits,
@@ -803,6 +874,20 @@ struct aic_lstm {
   const uint16_t* mlp_ln_w[8] = {};
   const uint16_t* mlp_ln_b[8] = {};
   std::vector<void*> mlp_owned;
+  // stacked sum_rnn stages (aic_mlp_create_stacked): per head and stage the LayerNorm parameters (caller-owned) and the
+  // fragment-major copy of the Linear (owned); a second partial buffer and a fragment-major scratch activation
+  int st_emb = 0, st_proj = 0, st_ln = 0;
+  const uint16_t* st_emb_ln_w[8][3] = {};
+  const uint16_t* st_emb_ln_b[8][3] = {};
+  uint4* st_emb_lin[8][3] = {};
+  const uint16_t* st_proj_ln_w[8][3] = {};
+  const uint16_t* st_proj_ln_b[8][3] = {};
+  uint4* st_proj_lin[8][3] = {};
+  uint4* st_ln_lin[8][3] = {};
+  const uint16_t* st_ln_ln_w[8][3] = {};
+  const uint16_t* st_ln_ln_b[8][3] = {};
+  float* part2 = nullptr;
+  uint4* tmp_frag = nullptr;
 };
 
 static int pad_mt(int batch) { return batch <= 16 ? 1 : (batch <= 32 ? 2 : 4); }
@@ -821,6 +906,92 @@ static int launch_gemm(int mt, dim3 grid, hipStream_t s, const uint4* W, const u
   return launch_status("skinny_gemm_kernel");
 }
 
+// LM head + arg-max of an MLP-class speculator from the state in h_bf16 (amax in m->amax[head])
+static int run_mlp_lm_head(aic_lstm* m, int head_index, hipStream_t s, int64_t* out_tokens, int out_stride, int out_col,
+                           float* out_vals) {
+  const aic_lstm_config& c = m->cfg;
+  const int mt = m->cur_mt, mpad = mt * 16, B = m->cur_batch, Ds = c.inner_dim;
+  int rc;
+  const bool fp8m = m->mlp_head8_t[head_index] && mpad <= c.head_fp8_max_batch;
+  dim3 hgrid(m->head_blocks, 1);
+  if (fp8m) {
+    hipLaunchKernelGGL(quant_act_kernel, dim3(64), dim3(256), 0, s, m->h_bf16, m->h_fp8, m->amax + head_index, m->x_scale, Ds,
+                       mt);
+    if ((rc = launch_status("quant_act_kernel")) != AIC_OK) return rc;
+    rc = launch_gemm<true, 1>(mt, hgrid, s, m->mlp_head8_t[head_index], m->h_fp8, m->head_rowtiles, Ds / 64, Ds / 64, nullptr,
+                              0, m->x_scale, m->mlp_head8_scale[head_index], c.vocab_size, c.vocab_offset, m->best_val,
+                              m->best_idx);
+  } else {
+    rc = launch_gemm<false, 1>(mt, hgrid, s, m->mlp_head_t[head_index], m->h_bf16, m->head_rowtiles, Ds / 32, Ds / 32, nullptr,
+                               0, nullptr, 1.0f, c.vocab_size, c.vocab_offset, m->best_val, m->best_idx);
+  }
+  if (rc != AIC_OK) return rc;
+  hipLaunchKernelGGL(argmax_finish_kernel, dim3(mpad), dim3(256), 0, s, m->best_val, m->best_idx, m->head_blocks, mpad, B,
+                     m->tokens, out_tokens, out_stride, out_col, out_vals);
+  return launch_status("argmax_finish_kernel");
+}
+
+// generate_states of a stacked sum_rnn head (arctic_speculator.py:693-703 over the Sequentials of :478-542): leaves the new
+// state fragment-major in h_bf16 (+ its amax), like mlp_cell_kernel does for the plain form
+static int run_stacked_states(aic_lstm* m, int head, hipStream_t s) {
+  const aic_lstm_config& c = m->cfg;
+  const int mt = m->cur_mt, mpad = mt * 16, B = m->cur_batch, Ds = c.inner_dim;
+  const bool first = head == 0;
+  const int K0 = first ? c.input_hidden_dim : Ds;
+  int rc;
+  auto splits_for = [&](int K) {
+    int sp = m->gate_splits;
+    while (sp > 1 && ((K / 32) % (sp * kChunkSteps) != 0)) --sp;
+    return sp;
+  };
+  auto gemm = [&](const uint4* W, const uint4* X, int K, float* part, int* splits_out) -> int {
+    const int sp = splits_for(K);
+    *splits_out = sp;
+    const int rowtiles = Ds / 16;
+    return launch_gemm<false, 0>(mt, dim3((rowtiles + 3) / 4, sp), s, W, X, rowtiles, K / 32, (K / 32) / sp, part, Ds, nullptr,
+                                 1.0f, 0, 0, nullptr, nullptr);
+  };
+  auto stage = [&](StageSrc a, StageSrc b, int has_b, const uint16_t* lw, const uint16_t* lb, int do_ln, int do_gelu, uint4* out,
+                   unsigned int* amax) -> int {
+    hipLaunchKernelGGL(stage_kernel, dim3(mpad), dim3(1024), Ds * sizeof(float), s, a, b, has_b, m->alpha, m->tokens, mpad, B, lw,
+                       lb, do_ln, do_gelu, Ds, mt, out, amax);
+    return launch_status("stage_kernel");
+  };
+  const StageSrc none{nullptr, 0, nullptr, 0};
+  // z = emb(last_tokens): the table row (or the caller's looked-up rows), then (LayerNorm, GELU, Linear)*
+  const uint16_t* emb_src = m->ext_rows ? m->ext_rows : m->mlp_emb[head];
+  AIC_REQUIRE(emb_src, "head %d has no embedding table and no looked-up rows (aic_mlp_set_embedding_rows)", head);
+  StageSrc z{nullptr, 0, emb_src, m->ext_rows ? 0 : 1};
+  int z_splits = 1;
+  for (int j = 0; j < m->st_emb; ++j) {
+    if ((rc = stage(z, none, 0, m->st_emb_ln_w[head][j], m->st_emb_ln_b[head][j], 1, 1, m->tmp_frag, nullptr)) != AIC_OK) return rc;
+    if ((rc = gemm(m->st_emb_lin[head][j], m->tmp_frag, Ds, m->part2, &z_splits)) != AIC_OK) return rc;
+    z = StageSrc{m->part2, z_splits, nullptr, 0};
+  }
+  // states = proj(prev), then (LayerNorm, GELU, Linear)*
+  int s_splits = 1;
+  if ((rc = gemm(m->mlp_proj_t[head], first ? m->x0 : m->h_bf16, K0, m->part, &s_splits)) != AIC_OK) return rc;
+  for (int j = 0; j < m->st_proj; ++j) {
+    if ((rc = stage(StageSrc{m->part, s_splits, nullptr, 0}, none, 0, m->st_proj_ln_w[head][j], m->st_proj_ln_b[head][j], 1, 1,
+                    m->tmp_frag, nullptr)) != AIC_OK)
+      return rc;
+    if ((rc = gemm(m->st_proj_lin[head][j], m->tmp_frag, Ds, m->part, &s_splits)) != AIC_OK) return rc;
+  }
+  // states.add_(z, alpha); y = ln[0](states); then (GELU, Linear, LayerNorm)*; state = GELU(y)
+  const bool plain_ln = m->st_ln == 0;
+  if ((rc = stage(StageSrc{m->part, s_splits, nullptr, 0}, z, 1, m->mlp_ln_w[head], m->mlp_ln_b[head], 1, 1,
+                  plain_ln ? m->h_bf16 : m->tmp_frag, plain_ln ? m->amax + head : nullptr)) != AIC_OK)
+    return rc;
+  for (int j = 0; j < m->st_ln; ++j) {
+    if ((rc = gemm(m->st_ln_lin[head][j], m->tmp_frag, Ds, m->part, &s_splits)) != AIC_OK) return rc;
+    const bool last = j + 1 == m->st_ln;
+    if ((rc = stage(StageSrc{m->part, s_splits, nullptr, 0}, none, 0, m->st_ln_ln_w[head][j], m->st_ln_ln_b[head][j], 1, 1,
+                    last ? m->h_bf16 : m->tmp_frag, last ? m->amax + head : nullptr)) != AIC_OK)
+      return rc;
+  }
+  return AIC_OK;
+}
+
 static int run_head(aic_lstm* m, int head_index, hipStream_t s, int64_t* out_tokens, int out_stride, int out_col,
                     float* out_vals) {
   const aic_lstm_config& c = m->cfg;
@@ -829,6 +1000,10 @@ static int run_head(aic_lstm* m, int head_index, hipStream_t s, int64_t* out_tok
   int rc;
   if (m->mlp) {
     AIC_REQUIRE(head_index < m->mlp_heads, "head %d of an MLP speculator with %d heads", head_index, m->mlp_heads);
+    if (m->st_emb + m->st_proj + m->st_ln > 0) {
+      if ((rc = run_stacked_states(m, head_index, s)) != AIC_OK) return rc;
+      return run_mlp_lm_head(m, head_index, s, out_tokens, out_stride, out_col, out_vals);
+    }
     // 1. projection (Ds x K), split-K partials in fp32;  2. + embedding, layer norm, gelu
     const bool first = head_index == 0;
     const int K = first ? c.input_hidden_dim : Ds;
@@ -1098,6 +1273,62 @@ int aic_mlp_create(const aic_lstm_config* cfg, const aic_mlp_weights* w, aic_lst
   return AIC_OK;
 }
 
+// aic_mlp_create + the extra stages of a stacked sum_rnn speculator.  Every width is inner_dim (the reference's LayerNorms
+// are built with the NEXT entry of the dimension list and applied to the previous stage's output, :488-492, so the lists can
+// only hold equal entries).
+int aic_mlp_create_stacked(const aic_lstm_config* cfg, const aic_mlp_weights* w, const aic_mlp_stack* st, aic_lstm** out) {
+  AIC_REQUIRE(st && st->n_emb >= 0 && st->n_emb <= 3 && st->n_proj >= 0 && st->n_proj <= 3 && st->n_ln >= 0 && st->n_ln <= 3,
+              "0..3 extra stages per stack");
+  int rc = aic_mlp_create(cfg, w, out);
+  if (rc != AIC_OK) return rc;
+  aic_lstm* m = *out;
+  const int Ds = cfg->inner_dim, mpad = m->max_mt * 16;
+  m->st_emb = st->n_emb;
+  m->st_proj = st->n_proj;
+  m->st_ln = st->n_ln;
+  std::vector<std::pair<const void*, uint4*>> seen;     // tied stages pass the same matrix: one fragment-major copy
+  auto repack = [&](const void* src, uint4** dst) -> int {
+    AIC_REQUIRE(src, "missing Linear weight of a stacked stage");
+    for (auto& kv : seen)
+      if (kv.first == src) {
+        *dst = kv.second;
+        return AIC_OK;
+      }
+    uint4* p = nullptr;
+    AIC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), static_cast<size_t>(Ds) * Ds * 2));
+    m->mlp_owned.push_back(p);
+    hipLaunchKernelGGL(repack_bf16_kernel, dim3(2048), dim3(256), 0, nullptr, static_cast<const uint16_t*>(src), p, Ds, Ds,
+                       Ds / 16);
+    seen.emplace_back(src, p);
+    *dst = p;
+    return launch_status("repack_bf16_kernel");
+  };
+  for (int i = 0; i < w->num_heads; ++i) {
+    for (int j = 0; j < st->n_emb; ++j) {
+      AIC_REQUIRE(st->emb_ln_w[i][j] && st->emb_ln_b[i][j], "missing LayerNorm of emb stage %d, head %d", j, i);
+      m->st_emb_ln_w[i][j] = static_cast<const uint16_t*>(st->emb_ln_w[i][j]);
+      m->st_emb_ln_b[i][j] = static_cast<const uint16_t*>(st->emb_ln_b[i][j]);
+      if ((rc = repack(st->emb_lin[i][j], &m->st_emb_lin[i][j])) != AIC_OK) return rc;
+    }
+    for (int j = 0; j < st->n_proj; ++j) {
+      AIC_REQUIRE(st->proj_ln_w[i][j] && st->proj_ln_b[i][j], "missing LayerNorm of proj stage %d, head %d", j, i);
+      m->st_proj_ln_w[i][j] = static_cast<const uint16_t*>(st->proj_ln_w[i][j]);
+      m->st_proj_ln_b[i][j] = static_cast<const uint16_t*>(st->proj_ln_b[i][j]);
+      if ((rc = repack(st->proj_lin[i][j], &m->st_proj_lin[i][j])) != AIC_OK) return rc;
+    }
+    for (int j = 0; j < st->n_ln; ++j) {
+      AIC_REQUIRE(st->ln_ln_w[i][j] && st->ln_ln_b[i][j], "missing LayerNorm of ln stage %d, head %d", j, i);
+      m->st_ln_ln_w[i][j] = static_cast<const uint16_t*>(st->ln_ln_w[i][j]);
+      m->st_ln_ln_b[i][j] = static_cast<const uint16_t*>(st->ln_ln_b[i][j]);
+      if ((rc = repack(st->ln_lin[i][j], &m->st_ln_lin[i][j])) != AIC_OK) return rc;
+    }
+  }
+  AIC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->part2), static_cast<size_t>(m->gate_splits) * mpad * Ds * 4));
+  AIC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->tmp_frag), static_cast<size_t>(mpad) * Ds * 2));
+  AIC_HIP_TRY(hipDeviceSynchronize());
+  return AIC_OK;
+}
+
 void aic_lstm_destroy(aic_lstm* m) {
   if (!m) return;
   void* bufs[] = {m->proj0_t, m->proj1_t, m->head_t, m->head8_t, m->x0,   m->h_bf16, m->h_fp8,
@@ -1106,6 +1337,8 @@ void aic_lstm_destroy(aic_lstm* m) {
     if (b) (void)hipFree(b);
   for (void* b : m->mlp_owned)
     if (b) (void)hipFree(b);
+  if (m->part2) (void)hipFree(m->part2);
+  if (m->tmp_frag) (void)hipFree(m->tmp_frag);
   delete m;
 }
 

@@ -353,7 +353,7 @@ class ArcticMLPSpeculator(ArcticLSTMSpeculator):
             wt.head[i] = W["head"][i].data_ptr()
         h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            N.check(N.lib().aic_mlp_create(ctypes.byref(cfg), ctypes.byref(wt), ctypes.byref(h)))
+            N.check(self._native_create(cfg, wt, h))
         self._h = h
         W["proj"] = W["head"] = None      # the library keeps fragment-major copies; embeddings and norms stay as they are
         mb = self.max_batch
@@ -364,6 +364,9 @@ class ArcticMLPSpeculator(ArcticLSTMSpeculator):
             "vals": torch.zeros(mb, self.max_speculative_tokens, dtype=torch.float32, device=self.device),
         }
 
+
+    def _native_create(self, cfg, wt, h) -> int:
+        return N.lib().aic_mlp_create(ctypes.byref(cfg), ctypes.byref(wt), ctypes.byref(h))
 
     # -- C9: sharded embedding ---------------------------------------------------------------------------------
     def embedding_rows(self, head: int, last_tokens: torch.Tensor, batch: int) -> torch.Tensor:
@@ -463,17 +466,23 @@ class ArcticSumRNNSpeculator(ArcticMLPSpeculator):
     speculator's head with its own input width and Sequential-wrapped parameter names (`emb.{i}.0.weight`, `proj.{i}.0.weight`,
     `ln.{i}.0.weight|bias`).  Same stage tying (emb / ln / head stage 0, proj stages 0 and 1, :653-654), same ln0 input
     scaling, same vocab-parallel head and sharded embedding, so it runs on the MLP speculator's kernels unchanged.
-    The multi-entry dimension lists ("4096.4096": extra LayerNorm + GELU + Linear stacks inside emb / proj / ln, :478-542)
-    are not built: such a checkpoint is refused with a message."""
+
+    Multi-entry dimension lists ("4096.4096", :478-542) put extra stages inside the Sequentials — emb.i / proj.i become
+    [base, (LayerNorm, GELU, Linear)*] with parameters `{emb,proj}.i.{3j-2}.weight|bias` and `{emb,proj}.i.{3j}.weight`,
+    ln.i becomes [LayerNorm, (GELU, Linear, LayerNorm)*] with `ln.i.{3j-1}.weight` and `ln.i.{3j}.weight|bias`.  They run
+    on the skinny GEMM + one generic row kernel (aic_mlp_create_stacked).  Every entry of every list must be the same width:
+    the reference builds stage j's LayerNorm with entry j and applies it to entry j-1's output, and adds proj's output to
+    emb's, so nothing else can run there either."""
 
     def __init__(self, config: LSTMSpeculatorConfig, **kw):
         inner, emb, proj = _dims(config.inner_dim), _dims(config.emb_dim), _dims(config.proj_dim)
-        if len(inner) != 1 or len(emb) != 1 or len(proj) != 1:
-            raise NotImplementedError("sum_rnn speculators with stacked emb / proj / ln stages (dimension lists with more "
-                                      f"than one entry: emb {emb}, proj {proj}, inner {inner}) are not supported")
-        if not (inner[0] == emb[0] == proj[0]):
-            raise ValueError("sum_rnn adds proj(prev) and emb(tokens): proj_dim, emb_dim and inner_dim must be equal "
-                             "(arctic_speculator.py:693-699)")
+        if len(set(inner + emb + proj)) != 1:
+            raise ValueError("sum_rnn adds proj(prev) and emb(tokens) and normalises stage outputs with the next entry's "
+                             f"LayerNorm: every entry of proj_dim {proj}, emb_dim {emb} and inner_dim {inner} must be equal "
+                             "(arctic_speculator.py:478-542, :693-699)")
+        if max(len(inner), len(emb), len(proj)) > 4:
+            raise NotImplementedError("at most three extra stages per stack")
+        self.stacks = (len(emb) - 1, len(proj) - 1, len(inner) - 1)
         self.lstm_config = config
         super().__init__(MLPSpeculatorConfig(vocab_size=config.vocab_size, emb_dim=config.input_hidden_dim,
                                              inner_dim=inner[0], n_predict=config.n_predict,
@@ -482,16 +491,63 @@ class ArcticSumRNNSpeculator(ArcticMLPSpeculator):
 
     _SEQ = ("emb.", "proj.", "ln.")
 
+    @staticmethod
+    def plain_name(name: str) -> str:
+        """`speculator.` prefix dropped; the base module of a Sequential (index 0) takes the MLP speculator's flat name:
+        emb.2.0.weight -> emb.2.weight; the extra stages keep their Sequential index (emb.2.3.weight)."""
+        name = name.replace("speculator.", "")
+        for pre in ArcticSumRNNSpeculator._SEQ:
+            if name.startswith(pre):
+                parts = name.split(".")
+                if len(parts) == 4 and parts[2] == "0":
+                    return ".".join(parts[:2] + parts[3:])
+        return name
+
     def load_weights(self, weights: Iterable[Tuple[str, torch.Tensor]]):
-        def plain(name: str) -> str:
-            name = name.replace("speculator.", "")
-            for pre in self._SEQ:                      # emb.2.0.weight -> emb.2.weight (index 0 of the nn.Sequential)
-                if name.startswith(pre):
-                    parts = name.split(".")
-                    if len(parts) == 4 and parts[2] == "0":
-                        return ".".join(parts[:2] + parts[3:])
-            return name
-        return super().load_weights((plain(k), v) for k, v in weights)
+        named = collections.OrderedDict((self.plain_name(k), v) for k, v in weights)
+        self._stack_weights = None
+        if any(self.stacks):
+            Ds, dev = self.inner_dim, self.device
+            bf = lambda t: t.to(device=dev, dtype=torch.bfloat16).contiguous()
+            cache: Dict[str, torch.Tensor] = {}
+
+            def take(name, shape):
+                if name not in cache:
+                    if name not in named:
+                        raise KeyError(f"speculator checkpoint is missing '{name}'")
+                    assert tuple(named[name].shape) == tuple(shape), (name, tuple(named[name].shape), tuple(shape))
+                    cache[name] = bf(named[name])
+                return cache[name]
+
+            k = self.max_speculative_tokens
+            sw = {key: [[None] * 3 for _ in range(k)] for key in ("emb_ln_w", "emb_ln_b", "emb_lin", "proj_ln_w", "proj_ln_b",
+                                                                  "proj_lin", "ln_lin", "ln_ln_w", "ln_ln_b")}
+            for i in range(k):
+                for kind, n in (("emb", self.stacks[0]), ("proj", self.stacks[1])):
+                    st = self._stage(i, kind)
+                    for j in range(1, n + 1):          # Sequential: ..., LayerNorm (3j-2), GELU, Linear (3j)
+                        sw[f"{kind}_ln_w"][i][j - 1] = take(f"{kind}.{st}.{3 * j - 2}.weight", (Ds,))
+                        sw[f"{kind}_ln_b"][i][j - 1] = take(f"{kind}.{st}.{3 * j - 2}.bias", (Ds,))
+                        sw[f"{kind}_lin"][i][j - 1] = take(f"{kind}.{st}.{3 * j}.weight", (Ds, Ds))
+                st = self._stage(i, "ln")
+                for j in range(1, self.stacks[2] + 1):  # Sequential: LayerNorm, then GELU, Linear (3j-1), LayerNorm (3j)
+                    sw["ln_lin"][i][j - 1] = take(f"ln.{st}.{3 * j - 1}.weight", (Ds, Ds))
+                    sw["ln_ln_w"][i][j - 1] = take(f"ln.{st}.{3 * j}.weight", (Ds,))
+                    sw["ln_ln_b"][i][j - 1] = take(f"ln.{st}.{3 * j}.bias", (Ds,))
+            self._stack_weights = sw
+        return super().load_weights(named.items())
+
+    def _native_create(self, cfg, wt, h) -> int:
+        if not any(self.stacks):
+            return super()._native_create(cfg, wt, h)
+        st = N.MlpStack()
+        st.n_emb, st.n_proj, st.n_ln = self.stacks
+        for key, rows in self._stack_weights.items():
+            field = getattr(st, key)
+            for i, row in enumerate(rows):
+                for j, t in enumerate(row):
+                    field[i][j] = None if t is None else t.data_ptr()
+        return N.lib().aic_mlp_create_stacked(ctypes.byref(cfg), ctypes.byref(wt), ctypes.byref(st), ctypes.byref(h))
 
 
 def lstm_family_speculator(config: LSTMSpeculatorConfig, **kw):

@@ -294,6 +294,18 @@ typedef struct aic_mlp_weights {
   const void* head[8];      /* bf16 [V_local, Ds] */
 } aic_mlp_weights;
 int aic_mlp_create(const aic_lstm_config* cfg, const aic_mlp_weights* w, aic_lstm** out);
+/* The LSTM class's "sum_rnn" form with multi-entry dimension lists ("4096.4096": arctic_speculator.py:478-542): emb.i and
+ * proj.i are nn.Sequentials [base, (LayerNorm, GELU, Linear)*], ln.i is [LayerNorm, (GELU, Linear, LayerNorm)*]; the base
+ * modules are the aic_mlp_weights entries, the extra stages come here (per head i <= 8, stage j <= 3; bf16; every width is
+ * inner_dim; LayerNorm = MLPSpeculatorLayerNorm with scale and shift).  Tied stages pass the same pointers. */
+typedef struct aic_mlp_stack {
+  int32_t n_emb, n_proj, n_ln;       /* extra stages per stack, 0..3 */
+  int32_t pad;
+  const void* emb_ln_w[8][3];  const void* emb_ln_b[8][3];  const void* emb_lin[8][3];    /* [Ds], [Ds], [Ds, Ds] */
+  const void* proj_ln_w[8][3]; const void* proj_ln_b[8][3]; const void* proj_lin[8][3];
+  const void* ln_lin[8][3];    const void* ln_ln_w[8][3];   const void* ln_ln_b[8][3];
+} aic_mlp_stack;
+int aic_mlp_create_stacked(const aic_lstm_config* cfg, const aic_mlp_weights* w, const aic_mlp_stack* stack, aic_lstm** out);
 /* C9 (vocab_parallel_embedding.py:425-444): with the token embedding sharded over the speculator's TP group the caller
  * looks the rows up on its shard (zeros for tokens it does not own), all-reduces them, and hands the [batch][inner_dim]
  * bf16 rows to the next aic_lstm_head call of an MLP speculator; NULL goes back to the handle's own tables (which

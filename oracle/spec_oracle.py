@@ -108,9 +108,15 @@ def lstm_generate_proposals(w: Dict[str, torch.Tensor], input_ids: torch.Tensor,
 
 def mlp_generate_proposals(w: Dict[str, torch.Tensor], input_ids: torch.Tensor, hidden: torch.Tensor, k: int,
                            n_predict: int, inner_dim: int, tie_weights: bool, scale_input: bool = False,
-                           fp8_head: bool = False, return_logits: bool = False, forced_tokens: torch.Tensor = None):
+                           fp8_head: bool = False, return_logits: bool = False, forced_tokens: torch.Tensor = None,
+                           stacks: Tuple[int, int, int] = (0, 0, 0)):
     """ArcticMLPSpeculator.generate_states + generate_token_ids, tp_size == 1 (arctic_speculator.py:264-321), on CPU
-    bf16 with the module's parameter names (emb.i / proj.i / ln.i / head.i; tied models keep stage 0, proj 0 and 1)."""
+    bf16 with the module's parameter names (emb.i / proj.i / ln.i / head.i; tied models keep stage 0, proj 0 and 1).
+    `stacks` = (extra emb stages, extra proj stages, extra ln stages) of the LSTM class's "sum_rnn" form with multi-entry
+    dimension lists (arctic_speculator.py:478-542): emb.i / proj.i are nn.Sequentials [base, (LayerNorm, GELU, Linear)*]
+    with parameters `emb.i.{3j-2}.weight|bias`, `emb.i.{3j}.weight`; ln.i is [LayerNorm, (GELU, Linear, LayerNorm)*] with
+    `ln.i.{3j-1}.weight`, `ln.i.{3j}.weight|bias`; the base modules keep the names `emb.i.weight`, `proj.i.weight`,
+    `ln.i.weight|bias` here (the loader maps `*.0.*` to them)."""
     dt = torch.bfloat16
     state_weight = 0.5 ** (0.5 / n_predict)
     emb_weight = math.sqrt((1 - state_weight ** 2) * (inner_dim / 2))
@@ -122,10 +128,22 @@ def mlp_generate_proposals(w: Dict[str, torch.Tensor], input_ids: torch.Tensor, 
     for i in range(k):
         if i == 0 and scale_input:
             prev = _l2norm(prev) / SQRT2
-        z = torch.nn.functional.embedding(last, w[f"emb.{stage(i, 'emb')}.weight"].to(dt))
-        states = torch.nn.functional.linear(prev, w[f"proj.{stage(i, 'proj')}.weight"].to(dt))
+        F = torch.nn.functional
+        se, sp, sl = stage(i, 'emb'), stage(i, 'proj'), stage(i, 'ln')
+        z = F.embedding(last, w[f"emb.{se}.weight"].to(dt))
+        for j in range(1, stacks[0] + 1):          # Sequential: LayerNorm, GELU, Linear
+            z = F.linear(gelu(_l2norm(z, w[f"emb.{se}.{3 * j - 2}.weight"].to(dt), w[f"emb.{se}.{3 * j - 2}.bias"].to(dt))),
+                         w[f"emb.{se}.{3 * j}.weight"].to(dt))
+        states = F.linear(prev, w[f"proj.{sp}.weight"].to(dt))
+        for j in range(1, stacks[1] + 1):
+            states = F.linear(gelu(_l2norm(states, w[f"proj.{sp}.{3 * j - 2}.weight"].to(dt),
+                                           w[f"proj.{sp}.{3 * j - 2}.bias"].to(dt))), w[f"proj.{sp}.{3 * j}.weight"].to(dt))
         states.add_(z, alpha=emb_weight / state_weight)
-        states = gelu(_l2norm(states, w[f"ln.{stage(i, 'ln')}.weight"].to(dt), w[f"ln.{stage(i, 'ln')}.bias"].to(dt)))
+        y = _l2norm(states, w[f"ln.{sl}.weight"].to(dt), w[f"ln.{sl}.bias"].to(dt))
+        for j in range(1, stacks[2] + 1):          # Sequential tail: GELU, Linear, LayerNorm
+            y = _l2norm(F.linear(gelu(y), w[f"ln.{sl}.{3 * j - 1}.weight"].to(dt)), w[f"ln.{sl}.{3 * j}.weight"].to(dt),
+                        w[f"ln.{sl}.{3 * j}.bias"].to(dt))
+        states = gelu(y)
         prev = states
         flat = states.flatten(0, 1)
         head_w = w[f"head.{stage(i, 'head')}.weight"].to(dt)

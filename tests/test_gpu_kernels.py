@@ -900,7 +900,7 @@ def test_mlp_speculator(B, tie, scale_input, fp8):
 def test_lstm_speculator_method_sum_rnn(tie):
     """ArcticLSTMSpeculator with method "sum_rnn" (the reference's default, arctic_speculator.py:441,691-703): the
     Sequential-named checkpoint (`emb.{i}.0.weight`, `proj.{i}.0.weight`, `ln.{i}.0.*`) loads through the LSTM class's
-    registry name and gives the op-sequence oracle's tokens; stacked stages are refused."""
+    registry name and gives the op-sequence oracle's tokens (stacked stages: the next test)."""
     from arcticinference_amd.speculator import (ArcticSumRNNSpeculator, LSTMSpeculatorConfig, MLPSpeculatorConfig,
                                                 lstm_family_speculator, random_mlp_weights)
     V, H, Ds, B = 3000, 768, 512, 9
@@ -923,6 +923,53 @@ def test_lstm_speculator_method_sum_rnn(tie):
     rerun = lambda forced: O.mlp_generate_proposals(ck, ids, hidden, 3, 3, Ds, tie, True, fp8_head=False, return_logits=True,
                                                     forced_tokens=forced)[1]
     _check_tokens(got, want, logits, f"sum_rnn tie={tie}", ulps=1, rerun=rerun)
+
+
+@pytest.mark.parametrize("stacks,tie,B,fp8", [((1, 1, 1), True, 9, False), ((2, 0, 1), False, 20, False), ((0, 1, 2), True, 5, True),
+                                              ((1, 0, 0), True, 33, False)])
+def test_lstm_speculator_sum_rnn_stacked_stages(stacks, tie, B, fp8):
+    """sum_rnn with multi-entry dimension lists (arctic_speculator.py:478-542): extra (LayerNorm, GELU, Linear) stages
+    inside emb / proj and (GELU, Linear, LayerNorm) stages inside ln, with the reference's Sequential parameter names,
+    against the CPU bf16 op-sequence oracle — tied and untied, bf16 and fp8 head."""
+    from arcticinference_amd.speculator import (ArcticSumRNNSpeculator, LSTMSpeculatorConfig, MLPSpeculatorConfig,
+                                                lstm_family_speculator, random_mlp_weights)
+    V, H, Ds, k = 3000, 768, 512, 3
+    ck = random_mlp_weights(MLPSpeculatorConfig(vocab_size=V, emb_dim=H, inner_dim=Ds, n_predict=k, num_lookahead_tokens=k,
+                                                tie_weights=tie, scale_input=True), seed=7, std=0.05)
+    g = torch.Generator().manual_seed(11)
+    lin = lambda: (torch.randn(Ds, Ds, generator=g) * 0.06).to(torch.bfloat16)
+    lnw = lambda: (1.0 + 0.1 * torch.randn(Ds, generator=g)).to(torch.bfloat16)
+    lnb = lambda: (0.1 * torch.randn(Ds, generator=g)).to(torch.bfloat16)
+    stages = lambda kind: (range(2) if kind == "proj" else range(1)) if tie else range(k)
+    for kind, n in (("emb", stacks[0]), ("proj", stacks[1])):
+        for i in stages(kind):
+            for j in range(1, n + 1):
+                ck[f"{kind}.{i}.{3 * j - 2}.weight"], ck[f"{kind}.{i}.{3 * j - 2}.bias"] = lnw(), lnb()
+                ck[f"{kind}.{i}.{3 * j}.weight"] = lin()
+    for i in stages("ln"):
+        for j in range(1, stacks[2] + 1):
+            ck[f"ln.{i}.{3 * j - 1}.weight"] = lin()
+            ck[f"ln.{i}.{3 * j}.weight"], ck[f"ln.{i}.{3 * j}.bias"] = lnw(), lnb()
+    seq = {}
+    for name, v in ck.items():          # the reference's names: the base module of a Sequential is its index 0
+        parts = name.split(".")
+        seq["speculator." + (".".join(parts[:2] + ["0"] + parts[2:]) if parts[0] in ("emb", "proj", "ln") and len(parts) == 3
+                             else name)] = v
+    dims = lambda n: ".".join([str(Ds)] * (n + 1))
+    cfg = LSTMSpeculatorConfig(vocab_size=V, input_hidden_dim=H, inner_dim=dims(stacks[2]), emb_dim=dims(stacks[0]),
+                               proj_dim=dims(stacks[1]), n_predict=k, num_lookahead_tokens=k, tie_weights=tie,
+                               scale_input=True, method="sum_rnn")
+    m = lstm_family_speculator(cfg, max_num_seqs=64, device=DEV, quantize_lm_head=fp8)
+    assert isinstance(m, ArcticSumRNNSpeculator) and m.stacks == stacks
+    m.load_weights(seq.items())
+    hidden = torch.randn(B, H, generator=g).to(torch.bfloat16)
+    ids = torch.randint(0, V, (B,), generator=g)
+    use_fp8 = fp8 and B <= 32
+    kw = dict(fp8_head=use_fp8, return_logits=True, stacks=stacks)
+    want, logits = O.mlp_generate_proposals(ck, ids, hidden, k, k, Ds, tie, True, **kw)
+    got = m.generate_proposals(ids.to(DEV), hidden.to(DEV), k).cpu()
+    rerun = lambda forced: O.mlp_generate_proposals(ck, ids, hidden, k, k, Ds, tie, True, forced_tokens=forced, **kw)[1]
+    _check_tokens(got, want, logits, f"stacked sum_rnn {stacks} tie={tie}", ulps=4 if use_fp8 else 1, rerun=rerun)
 
 
 def test_mlp_speculator_sharded_embedding_c9():

@@ -185,8 +185,8 @@ def test_bench_starts_its_own_ranks(monkeypatch):
 
 
 def test_lstm_family_speculator_by_method():
-    """`method` of an ArcticLSTMSpeculator checkpoint (arctic_speculator.py:441): sum_lstm and sum_rnn build, stacked
-    sum_rnn stages and unknown methods are refused with a message.  (Construction only: no device is touched.)"""
+    """`method` of an ArcticLSTMSpeculator checkpoint (arctic_speculator.py:441): sum_lstm and sum_rnn build (stacked
+    sum_rnn stages included), unequal widths and unknown methods are refused with a message.  (Construction only: no device is touched.)"""
     from arcticinference_amd.speculator import (ArcticLSTMSpeculator, ArcticSumRNNSpeculator, LSTMSpeculatorConfig,
                                                 lstm_family_speculator)
     base = dict(vocab_size=1000, input_hidden_dim=768, n_predict=3, num_lookahead_tokens=3)
@@ -195,8 +195,14 @@ def test_lstm_family_speculator_by_method():
     assert isinstance(m, ArcticSumRNNSpeculator) and m.inner_dim == 512 and m.input_hidden_dim == 768 and not m.tie_weights
     assert type(lstm_family_speculator(LSTMSpeculatorConfig(inner_dim="512", emb_dim="512", proj_dim="512", **base))) \
         is ArcticLSTMSpeculator
-    with pytest.raises(NotImplementedError, match="stacked"):
-        lstm_family_speculator(LSTMSpeculatorConfig(inner_dim="512.512", emb_dim="512", proj_dim="512", method="sum_rnn", **base))
+    st = lstm_family_speculator(LSTMSpeculatorConfig(inner_dim="512.512", emb_dim="512", proj_dim="512.512.512", method="sum_rnn",
+                                                     **base))
+    assert isinstance(st, ArcticSumRNNSpeculator) and st.stacks == (0, 2, 1)      # extra stages per emb / proj / ln stack
+    with pytest.raises(NotImplementedError, match="three extra stages"):
+        lstm_family_speculator(LSTMSpeculatorConfig(inner_dim="512.512.512.512.512", emb_dim="512", proj_dim="512",
+                                                    method="sum_rnn", **base))
+    with pytest.raises(ValueError, match="must be equal"):
+        lstm_family_speculator(LSTMSpeculatorConfig(inner_dim="512.256", emb_dim="512", proj_dim="512", method="sum_rnn", **base))
     with pytest.raises(ValueError, match="must be equal"):
         lstm_family_speculator(LSTMSpeculatorConfig(inner_dim="512", emb_dim="256", proj_dim="512", method="sum_rnn", **base))
     with pytest.raises(ValueError, match="unknown speculator method"):
