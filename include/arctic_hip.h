@@ -347,7 +347,10 @@ int aic_lstm_head(aic_lstm* m, int head_index, const int32_t* last_tokens /* [B]
  *       AIC_ERR_UNSUPPORTED); block_size a multiple of 16.  kv_dtype BF16 or FP8_E4M3 (+ k_scale / v_scale
  *       device scalars).
  *     workspace >= aic_verify_attention_workspace_bytes(...), private to the call until it completes on
- *     `stream`.  Graph-capture safe.  Calls for one device come from one host thread at a time (the
+ *     `stream`.  Graph-capture safe: this entry point (no host-side request lists) is the form the vLLM
+ *     route records under a capturing stream — batch, num_tokens, max_q_len and max_seq_len are then upper
+ *     bounds of every replay, requests behind the live ones must have an empty query (query_start_loc
+ *     repeated) and are skipped.  Calls for one device come from one host thread at a time (the
  *     fallback that runs long drafts on a library-owned side stream shares its fork/join events).
  * ---------------------------------------------------------------------------------------- */
 size_t aic_verify_attention_workspace_bytes(int num_tokens, int num_q_heads, int head_size, int num_splits_max);
