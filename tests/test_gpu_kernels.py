@@ -583,6 +583,30 @@ def test_verify_attention_layers_graph_back_to_back_calls_keep_their_own_paramet
         lib.aic_debug_attn_graph(1)
 
 
+def test_verify_attention_ignores_empty_trailing_requests():
+    """What a full-graph replay looks like to the kernel: the launch was recorded for MORE requests than the step has —
+    the entries behind the live ones have an empty query (query_start_loc repeated), a zero length and a zeroed block-table
+    row — and for an upper bound of the context length.  The live requests' rows equal the oracle; nothing faults."""
+    D, Hq, Hkv = 128, 8, 2
+    q_lens, ctxs = [1, 1, 4, 1, 2], [300, 33, 64, 17, 1025]
+    q, kc, vc, bt, qsl = _attn_case(5, Hq, Hkv, D, q_lens, ctxs, 16, seed=9)
+    want = O.verify_attention(q, kc, vc, bt, ctxs, qsl, D ** -0.5)
+    B_cap = 12                                             # captured batch
+    bt_pad = torch.zeros(B_cap, bt.shape[1], dtype=torch.int32)
+    bt_pad[:5] = bt
+    seq = torch.tensor(ctxs + [0] * (B_cap - 5), dtype=torch.int32)
+    qsl_pad = torch.tensor(list(qsl) + [int(qsl[-1])] * (B_cap - 5), dtype=torch.int32)
+    T_cap = 16                                             # captured token count: rows behind the live ones are padding
+    q_pad = torch.zeros(T_cap, Hq, D, dtype=torch.bfloat16)
+    q_pad[:q.shape[0]] = q
+    out = torch.full((T_cap, Hq, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    _ops().verify_attention(q_pad.to(DEV), kc.to(DEV), vc.to(DEV), bt_pad.to(DEV), seq.to(DEV), qsl_pad.to(DEV), 4, 4096,
+                            D ** -0.5, out=out)
+    torch.cuda.synchronize()
+    got = out[:q.shape[0]].float().cpu()
+    assert torch.allclose(got, want, atol=1e-3, rtol=2 ** -8), float((got - want).abs().max())
+
+
 def test_verify_attention_unsupported_shapes():
     from arcticinference_amd._native import NativeError
     q, kc, vc, bt, qsl = _attn_case(1, 4, 1, 96, [2], [40], 16, seed=1)
