@@ -182,6 +182,12 @@ class HotPathEngine:
         # A/B reference)
         import os
         self._native_index = os.environ.get("AIC_ENGINE_NUMPY", "0") != "1"
+        # begin()'s phase streams, AIC_ENGINE_PHASE_STREAMS = 2 (default): what precedes the attention launches on a stream
+        # of its own; 0: every launch of a step on the caller's stream; 1: the acceptance after the attention on a third
+        # stream as well; 3: only that.  MEASURED (bench.py, two lanes, ms per round, two runs each): 0: 6.465 / 6.485,
+        # 1: 6.615 / 6.619 (the attention launches themselves slow down: 0.714 -> 0.70 of the HBM peak), 2: 6.409 / 6.436,
+        # 3: 6.493 / 6.482.
+        self._phase_streams = int(os.environ.get("AIC_ENGINE_PHASE_STREAMS", "2"))
         self.sp = 1 if ulysses is None else ulysses.sp_size
         self.suffix_cache = SuffixCache(spec.suffix_cache_max_depth) if (
             spec.enable_suffix_decoding or spec.method == "suffix") else None
@@ -304,6 +310,7 @@ class HotPathEngine:
             # draft-model step may come long after its first step
             L.out_pin = torch.empty(self.max_num_seqs * (MAX_SPEC_LEN + 2), dtype=torch.int32).pin_memory()
             L.out_ev = torch.cuda.Event()
+            L.prep_ev, L.attn_ev = torch.cuda.Event(), torch.cuda.Event()     # phase streams (begin())
             if self.drafter is not None:
                 k = self.spec.num_speculative_tokens
                 L.lstm_pin = [torch.empty(self.max_num_seqs, k, dtype=torch.int64).pin_memory() for _ in range(2)]
@@ -374,21 +381,56 @@ class HotPathEngine:
         oa, ob = L.offs_a, L.offs_b
         if getattr(self, "qlen_hist", None) is not None:      # diagnostic (bench.py --qlen-hist): query lengths seen
             self.qlen_hist += np.bincount(n_draft + 1, minlength=len(self.qlen_hist))[:len(self.qlen_hist)]
-        devA[:bytes_a].copy_(pinA[:bytes_a], non_blocking=True)
+        # Phase streams (interleaved lanes only): the step's small launches before the attention — staging copy, block-table
+        # gather, KV write — are each a few microseconds of GPU work with 15-40 us of queue latency between them
+        # (rocprofv3 timeline, profiles/r03_step_timeline.txt: 0.29 ms of idle queue per round).  On a stream of their own
+        # they run beside the OTHER lane's attention launches.  The same for the acceptance behind the attention was
+        # measured and is not the default (see __init__).
+        main = torch.cuda.current_stream()
+        phased = self._phase_streams and len(self.__dict__.get("_lanes", ())) > 1
+        prep = self._side_stream("prep") if (phased and self._phase_streams != 3) else main
         view = lambda buf, off, n, dt, isz: buf[off:off + n * isz].view(dt)
-        d_seq = view(devA, int(oa[0]), B, torch.int32, 4)
-        d_qsl = view(devA, int(oa[1]), B + 1, torch.int32, 4)
-        slots = view(devA, int(oa[2]), B, torch.int64, 8)
-        d_slots = view(devA, int(oa[3]), T, torch.int64, 8)
-        order_dev = view(devA, int(oa[4]), B, torch.int32, 4)
-        bt = self.block_table.index_select(0, slots) if B != self.max_num_seqs else self.block_table
-        self._write_kv(d_slots, T)
+        with torch.cuda.stream(prep):
+            devA[:bytes_a].copy_(pinA[:bytes_a], non_blocking=True)
+            d_seq = view(devA, int(oa[0]), B, torch.int32, 4)
+            d_qsl = view(devA, int(oa[1]), B + 1, torch.int32, 4)
+            slots = view(devA, int(oa[2]), B, torch.int64, 8)
+            d_slots = view(devA, int(oa[3]), T, torch.int64, 8)
+            order_dev = view(devA, int(oa[4]), B, torch.int32, 4)
+            bt = self.block_table.index_select(0, slots) if B != self.max_num_seqs else self.block_table
+            self._write_kv(d_slots, T)
+            if prep is not main:
+                L.prep_ev.record()
+        if prep is not main:
+            if bt is not self.block_table:
+                bt.record_stream(main)       # allocated on the prep stream, read by the attention launches
+            main.wait_event(L.prep_ev)
         _mark('host_prepare')
         self._req_split = (order_dev[:n_short_reqs], n_short_reqs, order_dev[n_short_reqs:], B - n_short_reqs)
-        self._stream = int(torch.cuda.current_stream().cuda_stream)   # looked up once per step, not once per layer
+        self._stream = int(main.cuda_stream)   # looked up once per step, not once per layer
         self._attention_layers(T, bt, d_seq, d_qsl, max_q, max_ctx)
         self.last_ctx_sum = int(L.ctx_sum[0])
         _mark('enqueue_attention')
+        post = main
+        if phased and self._phase_streams != 2:
+            L.attn_ev.record()
+            post = self._side_stream("post")
+            post.wait_event(L.attn_ev)       # the acceptance follows the step's attention (and the previous draft-model run)
+        with torch.cuda.stream(post):
+            return self._begin_tail(next_truth, L, live, reqs, B, T, D, F, n_draft, max_q, bytes_b, prev_lstm, _mark, main, post)
+
+    def _side_stream(self, name: str):
+        streams = self.__dict__.setdefault("_side_streams", {})
+        if name not in streams:
+            streams[name] = torch.cuda.Stream(device=self.device)
+        return streams[name]
+
+    def _begin_tail(self, next_truth, L, live, reqs, B, T, D, F, n_draft, max_q, bytes_b, prev_lstm, _mark, main, post):
+        """begin() after the attention launches, on the stream the caller made current: staging B, acceptance, the copy of
+        the accepted tokens to the host."""
+        pinB, devB = L.stage["B"]
+        ob = L.offs_b
+        view = lambda buf, off, n, dt, isz: buf[off:off + n * isz].view(dt)
         # ---- staging B (the GPU is busy with the attention launches from here on): only the synthetic target's tokens
         # are missing from it — row (request i, position p) gets the target's token for that position
         ql = (n_draft + 1).tolist()
@@ -407,8 +449,16 @@ class HotPathEngine:
             d_fpos, d_fsrc = view(devB, int(ob[5]), F, torch.int64, 8), view(devB, int(ob[6]), F, torch.int64, 8)
             d_draft.index_copy_(0, d_fpos, prev_lstm.reshape(-1).index_select(0, d_fsrc).to(torch.int32))
         _mark('stage_acceptance')
-        return self._begin_accept(L, live, reqs, B, T, n_draft, max(max_q - 1, 1), d_draft, d_cu, d_plant, d_trows, d_brows,
-                                  _mark)
+        c = self._begin_accept(L, live, reqs, B, T, n_draft, max(max_q - 1, 1), d_draft, d_cu, d_plant, d_trows, d_brows,
+                               _mark)
+        if post is not main:
+            # the acceptance's outputs live in the post stream's pool; the draft model reads them on the main stream (after
+            # the host has waited for out_ev)
+            for t in (c.rej.last_token, c.rej.hidden_index):
+                if t is not None:
+                    t.record_stream(main)
+            c.draft_stream = post if c.lstm_out is not None else None
+        return c
 
     def _begin_numpy(self, next_truth, L, live, reqs, n_draft, G, _mark):
         """begin() with the index arrays built by numpy (AIC_ENGINE_NUMPY=1: the A/B reference of the native build)."""
@@ -517,7 +567,7 @@ class HotPathEngine:
                                                        hidden_index=rej.hidden_index)
         _mark('enqueue_accept_and_draft')
         return SimpleNamespace(lane=L, live=live, reqs=reqs, B=B, n_draft=n_draft, out_pin=out_pin, rej=rej, lstm_out=lstm_out,
-                               use_lstm=use_lstm)
+                               use_lstm=use_lstm, draft_stream=None)
 
     def finish(self, c) -> List[List[int]]:
         """Host half of the step begun as `c`: returns the tokens emitted per request of that step."""
@@ -619,9 +669,12 @@ class HotPathEngine:
                               for _ in range(2)]
             L.lstm_flip ^= 1
             pin = L.lstm_pin[L.lstm_flip][:B]              # two buffers: the previous step's copy may still be unread
-            pin.copy_(lstm_out, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
+            # (an early draft ran on begin()'s post stream: its copy goes behind it there)
+            early_on = c.draft_stream if (lstm_out is c.lstm_out and c.draft_stream is not None) else torch.cuda.current_stream()
+            with torch.cuda.stream(early_on):
+                pin.copy_(lstm_out, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
         L.lstm_prev = lstm_out
         _mark('host_draft_copy')
         room = np.maximum(self.max_model_len - end_prop - 1, 0)
