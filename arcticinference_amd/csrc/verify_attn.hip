@@ -1359,6 +1359,11 @@ static int g_force_hpw = 0, g_force_splits = 0;   // aic_debug_attn_layout (tool
 // i.e. what a workgroup reads per token (HPW x 256 contiguous bytes: DRAM page locality) outweighs the partial write and
 // the combine launch that cross-workgroup splits cost.  So: as many heads per workgroup as divide the head count, splits
 // by pick_splits, and the direct form whenever that leaves a single split (many requests, or few heads per rank).
+// r03 also built the next step of that series — EIGHT waves per workgroup, one per kv head (512 threads, 2 KiB contiguous per
+// token with a bf16 cache, 1 KiB with fp8; 215-242 VGPRs, no spills, two waves per SIMD) — and measured it on short-only calls
+// (tools/microbench.py fp8layout, profiles/r03_layout8_experiment.txt): fp8 cache 64 requests 95.5 against 95.7 us, 32 requests
+// 53.8 against 51.6; bf16 cache 179.5 against 171.5 and 98.0 against 91.3.  Not kept: the four-wave form already streams at
+// what the memory system gives (6.2 TB/s bf16, 5.9 TB/s fp8 without the combine launch).
 struct ShortLayout {
   int hpw, splits;
 };

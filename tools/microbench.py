@@ -245,6 +245,19 @@ if __name__ == "__main__":
             print(f"layout hpw={hpw} splits=auto: ", end="")
             attn_mix(64, 0, Hq=8, Hkv=2)
         N.lib().aic_debug_attn_layout(0, 0)
+    if "fp8layout" in what:   # the fp8 short body is issue-bound, not HBM-bound: does a second workgroup per CU pay there?
+        attn_mix(64, 0, kv8=True)       # (first case of a process: clocks still ramping)
+        for B, combos in ((64, ((0, 0), (4, 2), (4, 4), (4, 8))), (32, ((0, 0), (4, 4), (4, 8), (4, 16))), (16, ((0, 0), (4, 16)))):
+            for hpw, sp in combos:
+                N.lib().aic_debug_attn_layout(hpw, sp)
+                print(f"fp8 layout hpw={hpw} splits={sp}: ", end="")
+                attn_mix(B, 0, kv8=True)
+        N.lib().aic_debug_attn_layout(0, 0)
+    if "fp8mix" in what:      # a 32-request lane with long drafts, fp8 cache against bf16
+        attn_mix(32, 0, kv8=True)
+        for kv8 in (True, False):
+            for ns, nl, qlong in ((32, 0, 33), (31, 1, 33), (30, 2, 33), (30, 2, 12), (28, 4, 20), (0, 1, 33), (0, 2, 33)):
+                attn_mix(ns, nl, q_long=qlong, kv8=kv8)
     if "pmc" in what:      # the cases whose kernels tools/pmc_kernels.py tells apart by name (few iterations: counters, not time)
         _t = timeit
         timeit = lambda fn, iters=4, warm=1: _t(fn, iters=4, warm=1)
