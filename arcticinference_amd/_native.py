@@ -66,6 +66,7 @@ _SIGNATURES = {
     "aic_device_count": (c_int, []),
     "aic_profile_enable": (c_int, [c_int]),
     "aic_profile_read": (c_int, [POINTER(c_double), POINTER(c_int)]),
+    "aic_profile_event_overhead": (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_double)]),
     "aic_st_create": (c_void_p, [c_int]),
     "aic_st_destroy": (None, [c_void_p]),
     "aic_st_num_seqs": (c_int, [c_void_p]),

@@ -1,6 +1,7 @@
 // Error channel and device probing shared by every entry point of libarctic_hip.so.
 #include "aic_common.h"
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <utility>
@@ -78,6 +79,47 @@ int aic_profile_read(double* total_us, int* launches) {
   if (total_us) *total_us = us;
   if (launches) *launches = n;
   aic::g_used = 0;
+  return AIC_OK;
+}
+// What the instrument itself reads: `pairs` event pairs recorded back to back on `stream` with NOTHING between the two
+// events of a pair (the distance of two consecutive marker packets).  bench.py reports it next to the raw average and
+// subtracts it, and checks the result against rocprofv3's kernel durations of the same command.
+int aic_profile_event_overhead(void* stream, int pairs, double* mean_us, double* min_us) {
+  AIC_REQUIRE(pairs > 0 && pairs <= 4096 && mean_us, "pairs in [1, 4096] and an output pointer");
+  AIC_NEED_DEVICE();
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev(static_cast<size_t>(pairs), {nullptr, nullptr});
+  int rc = AIC_OK;
+  for (auto& e : ev)
+    if (hipEventCreate(&e.first) != hipSuccess || hipEventCreate(&e.second) != hipSuccess) rc = AIC_ERR_HIP;
+  if (rc == AIC_OK) {
+    for (auto& e : ev)
+      if (hipEventRecord(e.first, s) != hipSuccess || hipEventRecord(e.second, s) != hipSuccess) rc = AIC_ERR_HIP;
+  }
+  double sum = 0.0, lo = 1e30;
+  int n = 0;
+  if (rc == AIC_OK) {
+    for (auto& e : ev) {
+      float ms = 0.0f;
+      if (hipEventSynchronize(e.second) != hipSuccess || hipEventElapsedTime(&ms, e.first, e.second) != hipSuccess) {
+        rc = AIC_ERR_HIP;
+        break;
+      }
+      sum += ms * 1000.0;
+      lo = std::min(lo, static_cast<double>(ms) * 1000.0);
+      ++n;
+    }
+  }
+  for (auto& e : ev) {
+    if (e.first) (void)hipEventDestroy(e.first);
+    if (e.second) (void)hipEventDestroy(e.second);
+  }
+  if (rc != AIC_OK) {
+    aic::set_error("HIP events failed while measuring the event-pair overhead: %s", hipGetErrorString(hipGetLastError()));
+    return rc;
+  }
+  *mean_us = sum / n;
+  if (min_us) *min_us = lo;
   return AIC_OK;
 }
 const char* aic_last_error(void) { return aic::g_err; }

@@ -472,6 +472,10 @@ def main():
     N.lib().aic_profile_read(ctypes.byref(tot_us), ctypes.byref(launches))
     N.lib().aic_profile_enable(0)
     graph1 = N.attn_graph_stats()
+    # what an event pair reads with nothing between its two events (the stream is idle now): the instrument's own offset
+    ev_mean, ev_min = ctypes.c_double(0), ctypes.c_double(0)
+    N.check(N.lib().aic_profile_event_overhead(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), 256,
+                                               ctypes.byref(ev_mean), ctypes.byref(ev_min)))
 
     red_dev = dev if args.dist_backend == "nccl" else "cpu"
     if dist is not None:
@@ -545,7 +549,11 @@ def main():
     if rank == 0:
         value = gen_total / elapsed
         st = stats_snapshot
+        # a timed launch = event, kernel, event.  `achieved` uses the pairs' reading AS IT IS (an upper bound of the kernel's
+        # duration: an empty pair on the same stream reads ~4.5 us by itself); the reading minus the empty pair's is reported
+        # beside it, and rocprofv3's kernel durations for this command (profiles/rNN_kernel_stats.csv) lie between the two
         avg_launch_us = tot_us.value / max(launches.value, 1)
+        net_launch_us = max(avg_launch_us - ev_mean.value, 0.0) if launches.value else 0.0
         # every launch of a lane's step moves that lane's bytes; n_lanes launches per layer and round
         bytes_per_launch = attn_bytes_timed / max(args.steps * shape.num_layers * n_lanes, 1)
         achieved = bytes_per_launch / (avg_launch_us * 1e-6) / 1e9 if launches.value else 0.0
@@ -650,10 +658,16 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_source,
                          "avg_launch_us": avg_launch_us, "launches_timed": launches.value,
+                         "empty_event_pair_us": ev_mean.value, "avg_launch_us_minus_empty_pair": net_launch_us,
+                         "frac_minus_empty_pair": (bytes_per_launch / (net_launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                                                   if net_launch_us > 0 else 0.0),
                          "launches": args.steps * shape.num_layers * n_lanes,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "every %d-th launch timed with a HIP event pair inside the library, on the launch's "
-                                 "stream%s; the kernel is verify_attn_pair_kernel (short-request and long-draft "
+                                 "stream%s; avg_launch_us and frac use the pairs' reading as it is; empty_event_pair_us = what a "
+                                 "pair with nothing between its events reads (256 pairs, same stream, after the timed region), "
+                                 "*_minus_empty_pair = with that subtracted — rocprofv3's kernel durations for the same command "
+                                 "(profiles/) lie between the two; the kernel is verify_attn_pair_kernel (short-request and long-draft "
                                  "workgroups in one grid) or verify_attn_kernel when a step has no long draft"
                                  % (PROFILE_STRIDE, "" if args.no_attn_graph else
                                     ", in every 5th engine step (those go out kernel by kernel; the other steps' layers are "

@@ -54,6 +54,9 @@ int aic_device_count(void);
  * stream; aic_profile_read synchronises them, returns {sum of microseconds, timed launches} and resets. */
 int aic_profile_enable(int on);
 int aic_profile_read(double* total_us, int* launches);
+/* The instrument's own reading: `pairs` (1..4096) event pairs recorded on `stream` with nothing between the two events
+ * of a pair; mean (and, if asked, minimum) elapsed microseconds.  Synchronises the stream's events. */
+int aic_profile_event_overhead(void* stream, int pairs, double* mean_us, double* min_us);
 
 /* ------------------------------------------------------------------------------------------
  * A1/A2  Suffix tree — replaces pybind module `_C` (csrc/suffix_cache/pybind.cc:24-38,
