@@ -315,9 +315,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     dist = None
-    if world > 1:
+    # AIC_BENCH_ONE_RANK_GROUP=1 (tests): a ONE-rank process group, so that the N > 1 code — group creation, the Ulysses
+    # context over a real group, barrier and the reductions of the result — runs through RCCL on a one-GPU box
+    one_rank_group = world == 1 and os.environ.get("AIC_BENCH_ONE_RANK_GROUP") == "1"
+    if world > 1 or one_rank_group:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.dist_backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(dev))
         else:
@@ -347,7 +351,7 @@ def main():
 
     ulysses = None
     tp_group = None
-    if world > 1:
+    if world > 1 or one_rank_group:
         from arcticinference_amd.ulysses import UlyssesContext
         ulysses = UlyssesContext(world, rank, dist.group.WORLD, shape, device=dev,
                                  enable_shift_parallel=not args.no_shift_parallel, shift_parallel_threshold=512)
