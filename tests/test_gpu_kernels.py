@@ -1127,3 +1127,34 @@ def test_lstm_vocab_parallel_shards_agree_with_single_rank():
             last = nxt.to(torch.int32)
         got = torch.cat(outs, dim=-1).cpu()
         assert torch.equal(got, want), (tp, got, want)
+
+
+def test_profile_event_pairs_time_the_attention_launches():
+    """bench.py's roofline instrument: with aic_profile_enable(n) every n-th attention launch is bracketed by an event pair
+    on its stream; aic_profile_event_overhead is what a pair reads with nothing inside."""
+    import ctypes
+    from arcticinference_amd import _native as N
+    ops = _ops()
+    lib = N.lib()
+    torch.manual_seed(0)
+    B, ctx, Hq, Hkv, D, bs = 8, 512, 8, 2, 128, 16
+    nblk = ctx // bs
+    kv = torch.randn(2, B * nblk, bs, Hkv, D, device=DEV, dtype=torch.bfloat16)
+    bt = torch.arange(B * nblk, device=DEV, dtype=torch.int32).view(B, nblk)
+    q = torch.randn(B, Hq, D, device=DEV, dtype=torch.bfloat16)
+    seq = torch.full((B,), ctx, dtype=torch.int32, device=DEV)
+    qsl = torch.arange(B + 1, dtype=torch.int32, device=DEV)
+    N.check(lib.aic_profile_enable(2))
+    try:
+        for _ in range(6):
+            ops.verify_attention(q, kv[0], kv[1], bt, seq, qsl, 1, ctx, D ** -0.5)
+        tot, n = ctypes.c_double(0), ctypes.c_int(0)
+        N.check(lib.aic_profile_read(ctypes.byref(tot), ctypes.byref(n)))
+    finally:
+        N.check(lib.aic_profile_enable(0))
+    assert n.value == 3 and 0.0 < tot.value / n.value < 5e3           # every 2nd of 6 launches, microseconds each
+    mean, lo = ctypes.c_double(0), ctypes.c_double(0)
+    N.check(lib.aic_profile_event_overhead(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), 64, ctypes.byref(mean),
+                                           ctypes.byref(lo)))
+    assert 0.0 <= lo.value <= mean.value < 200.0
+    assert lib.aic_profile_event_overhead(None, 0, ctypes.byref(mean), None) != 0      # pairs must be >= 1
