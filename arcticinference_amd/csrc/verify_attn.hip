@@ -1347,6 +1347,7 @@ static int g_attn_trace_cap = 0;
 static int g_long_splits = 0; // aic_debug_attn_long_splits: split count of the long-draft part of a mixed call (0 = the default)
 static int g_light_pct = 0;   // aic_debug_attn_light: weight of the light splits in percent (0 = the default, 100 = off)
 static int g_force_hpw = 0, g_force_splits = 0;   // aic_debug_attn_layout (tools/microbench.py sweeps); 0 = choose
+static int g_force_sequential = -1;               // aic_debug_attn_sequential: 1 / 0 = always / never the two-launch form of a mixed call
 
 // Layout of the short body for a call whose query lengths the host knows: kv heads per workgroup (4, 2 or 1: the four
 // waves are HPW head groups of R = 4 / HPW token ranges each, merged through LDS) and cross-workgroup token splits.
@@ -1392,6 +1393,13 @@ int aic_debug_attn_trace(int64_t* buf, int capacity_wgs) {
 // one-grid launch; 0 = the built-in value, 100 = equal splits
 int aic_debug_attn_light(int pct) {
   g_light_pct = pct;
+  return AIC_OK;
+}
+
+// debug: 1 = every mixed call as two launches (long part, then short part), 0 = the one-grid form whenever it fits,
+// -1 = choose (the default); every setting computes the same result
+int aic_debug_attn_sequential(int mode) {
+  g_force_sequential = mode;
   return AIC_OK;
 }
 
@@ -1503,6 +1511,24 @@ int aic_verify_attention_win(const void* q, int64_t q_stride, const void* k_cach
     }
     n_splits_long = std::min(n_splits_long, cap);
   }
+  // Many long drafts in one call (a lane step in which suffix decoding hit for half the requests): the one-grid form —
+  // every workgroup resident at once, two per CU — has room for ONE split of the long part only, every long workgroup then
+  // walks a whole context alone, and the launch takes as long as that walk (rocprofv3 of the r03 bench: 15 long + 17 short
+  // requests, 400 workgroups, 240 us per layer where the usual mixes take 90-103).  Such a call goes out as two plain
+  // launches on the same stream instead, the long part with the split count it would have alone, then the short part
+  // (16 long drafts alone take 105 us, 17 short requests ~50).
+  bool sequential = false;
+  if (mixed && !d64) {
+    const int long_z_ = (max_rows + 4 * kLongTilesPerWave * 16 - 1) / (4 * kLongTilesPerWave * 16);
+    const int short_wg_ = (n_short * hgroups_s + 7) / 8 * 8 * n_splits;
+    const int per_split_ = n_long * num_kv_heads * long_z_;
+    const int fit = (2 * cu_count() - short_wg_) / per_split_;
+    const bool want = g_force_sequential >= 0 ? g_force_sequential == 1 : (fit == 1 && n_splits_long >= 2);
+    if (fit < 1 || want) {
+      sequential = true;
+      n_splits_long = pick_splits(n_long * num_kv_heads, max_seq_len, 8, 2);
+    }
+  }
   auto fits = [&](int parts) { return static_cast<size_t>(parts) * rows * (head_size + 2) * sizeof(float) <= workspace_bytes; };
   while (n_splits > 1 && !fits(n_splits)) --n_splits;
   while (n_splits_long > 1 && !fits(n_splits_long)) --n_splits_long;
@@ -1589,6 +1615,7 @@ int aic_verify_attention_win(const void* q, int64_t q_stride, const void* k_cach
     // the long part take the whole chip first — 2 workgroups per CU, the short ones dispatched as those retire — was
     // measured and is worse: 59 short + 5 long 214 us against 206 us, and the bench's real mix 267 us against 182 us.)
     bool pair = n_short > 0 && n_long > 0 && !d64;   // (the one-grid form is instantiated for head size 128)
+    if (sequential) pair = false;
     if (pair) {
       const int room = 2 * cu_count() - short_wg;
       const int per_split = n_long * num_kv_heads * long_z;
@@ -1639,7 +1666,7 @@ int aic_verify_attention_win(const void* q, int64_t q_stride, const void* k_cach
       if (!t_rec) profile_end(s);
       n_short = n_long = 0;  // both done
     }
-    const bool overlap = n_short > 0 && n_long > 0;
+    const bool overlap = n_short > 0 && n_long > 0 && !sequential;   // (head size 64: long part beside the short one on a side stream)
     const bool short_first = false;
     if (overlap && t_rec) {      // a fork / join over the side stream is not a plain kernel chain
       t_rec->ok = false;

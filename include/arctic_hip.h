@@ -164,6 +164,10 @@ int aic_debug_attn_trace(int64_t* buf, int capacity_wgs);
 /* debug aid: force the short attention body's kv heads per workgroup (4 / 2 / 1) and / or its cross-workgroup split count
  * for host-partitioned calls (0 = chosen by the library); every setting computes the same result. */
 int aic_debug_attn_layout(int heads_per_wg, int splits);
+/* debug aid: a call with short requests AND long drafts goes out as one grid, or — when the grid has room for a single split of
+ * the long part only — as two launches on the same stream (long part, then short part).  1 / 0 = always / never two launches,
+ * -1 = chosen by the library; every setting computes the same result. */
+int aic_debug_attn_sequential(int mode);
 /* debug aid: share (percent) of a full token-range split that a short workgroup takes when it will share its CU with a
  * long-draft workgroup of the one-grid launch (0 = the built-in 88, 100 = equal splits); every setting computes the same
  * result. */

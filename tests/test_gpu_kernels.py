@@ -745,6 +745,73 @@ def test_verify_attention_lighter_trailing_splits():
         assert torch.allclose(outs[0][rows].cpu(), want, atol=1e-3, rtol=2 ** -8), (i, (outs[0][rows].cpu() - want).abs().max())
 
 
+@pytest.mark.parametrize("n_long,kv", [(15, "bf16"), (20, "bf16"), (31, "bf16"), (16, "fp8")])
+def test_verify_attention_many_long_drafts_in_a_lane(n_long, kv):
+    """A lane step in which suffix decoding hit for half of the 32 requests or more: the one-grid launch would leave the
+    long part a single split (every long workgroup alone with a whole context), so the call goes out as two plain launches
+    on one stream — the long part with its own split count, then the short part.  Same attention as the generic path and
+    the oracle, and the run of layers is still one HIP graph launch (a plain kernel chain: no side stream)."""
+    import ctypes
+    from arcticinference_amd import _native as N
+    torch.manual_seed(3)
+    B, Hq, Hkv, D, bs = 32, 32, 8, 128, 16
+    rng = np.random.RandomState(n_long)
+    q_lens = [int(x) for x in rng.randint(9, 34, size=n_long)] + [int(x) for x in rng.choice([1, 1, 1, 4, 6, 8], size=B - n_long)]
+    rng.shuffle(q_lens)
+    ctxs = [int(x) for x in rng.randint(1500, 2400, size=B)]
+    max_blocks = max((c + bs - 1) // bs for c in ctxs)
+    nb = B * max_blocks
+    bt = torch.randperm(nb).view(B, max_blocks).to(torch.int32)
+    kw = {}
+    if kv == "fp8":
+        raw = torch.randint(0, 256, (2, nb, bs, Hkv, D), dtype=torch.uint8, device=DEV)
+        raw[(raw & 0x7f) == 0x7f] = 0x30
+        kc, vc = raw[0].view(torch.float8_e4m3fn), raw[1].view(torch.float8_e4m3fn)
+        sc = torch.full((1,), 0.03, dtype=torch.float32, device=DEV)
+        kw = dict(k_scale=sc, v_scale=sc)
+    else:
+        kc = torch.randn(nb, bs, Hkv, D, device=DEV, dtype=torch.bfloat16)
+        vc = torch.randn(nb, bs, Hkv, D, device=DEV, dtype=torch.bfloat16)
+    q = torch.randn(sum(q_lens), Hq, D, device=DEV, dtype=torch.bfloat16)
+    qsl = torch.tensor(np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32), device=DEV)
+    seq = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
+    ops = _ops()
+    dbt = bt.to(DEV)
+    part = ops.verify_attention(q, kc, vc, dbt, seq, qsl, max(q_lens), max(ctxs), D ** -0.5, q_lens_host=q_lens, **kw).float()
+    generic = ops.verify_attention(q, kc, vc, dbt, seq, qsl, max(q_lens), max(ctxs), D ** -0.5, **kw).float()
+    # (two bf16 results, each rounded once: up to one bf16 ulp apart in either direction)
+    assert torch.allclose(part, generic, atol=1e-3, rtol=2 ** -7), (part - generic).abs().max()
+    qs = qsl.cpu().numpy()
+    for i in (int(np.argmax(q_lens)), int(np.argmin(q_lens)), B - 1):
+        rows = slice(int(qs[i]), int(qs[i + 1]))
+        if kv == "fp8":
+            want = O.verify_attention(q[rows].cpu(), kc.cpu(), vc.cpu(), bt[i:i + 1], [ctxs[i]],
+                                      np.array([0, q_lens[i]], dtype=np.int32), D ** -0.5, 0.03, 0.03)
+        else:
+            want = O.verify_attention(q[rows].cpu(), kc.cpu(), vc.cpu(), bt[i:i + 1], [ctxs[i]],
+                                      np.array([0, q_lens[i]], dtype=np.int32), D ** -0.5)
+        assert torch.allclose(part[rows].cpu(), want, atol=1e-3, rtol=2 ** -8), (i, (part[rows].cpu() - want).abs().max())
+    # four layers in one call: one graph launch, bit-identical to the single calls
+    lib = N.lib()
+    a0, b0 = ctypes.c_uint64(), ctypes.c_uint64()
+    lib.aic_debug_attn_graph_stats(ctypes.byref(a0), ctypes.byref(b0))
+    L = 4
+    rs = ops.split_requests(q_lens, Hq // Hkv, DEV)
+    outs = torch.full((L,) + tuple(q.shape), float("nan"), device=DEV, dtype=q.dtype)
+    qs4 = torch.stack([q * (1.0 + 0.5 * l) for l in range(L)]).contiguous()
+    plan = ops.VerifyAttentionPlan(qs4[0], outs[0], kc, dbt, seq, qsl, max(q_lens), max(ctxs), D ** -0.5, req_split=rs, **kw)
+    a = plan._args
+    kt, vt, n, _keep = plan.layer_tables([kc] * L, [vc] * L)
+    N.check(lib.aic_verify_attention_layers(a[0], a[1], qs4.stride(0), kt, vt, n, *a[4:20], a[20], a[21], outs.stride(0), *a[22:]))
+    torch.cuda.synchronize()
+    a1, b1 = ctypes.c_uint64(), ctypes.c_uint64()
+    lib.aic_debug_attn_graph_stats(ctypes.byref(a1), ctypes.byref(b1))
+    assert a1.value - a0.value == 1, "the two-launch form must stay a plain kernel chain (one graph launch)"
+    for l in range(L):
+        want = ops.verify_attention(qs4[l], kc, vc, dbt, seq, qsl, max(q_lens), max(ctxs), D ** -0.5, req_split=rs, **kw)
+        assert torch.equal(outs[l], want), l
+
+
 @pytest.mark.parametrize("Hkv", [8, 1])
 def test_verify_attention_long_draft_split_counts(Hkv):
     """The long-draft part of a one-grid call takes 2-32 token-range splits by the load of the call (a rank of SP = 8 sees

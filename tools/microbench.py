@@ -253,6 +253,14 @@ if __name__ == "__main__":
                 print(f"fp8 layout hpw={hpw} splits={sp}: ", end="")
                 attn_mix(B, 0, kv8=True)
         N.lib().aic_debug_attn_layout(0, 0)
+    if "manylong" in what:    # a 32-request lane in which suffix decoding hit for many requests (one-grid form out of room)
+        for ns, nl, qlong in ((31, 1, 33), (28, 4, 20), (25, 7, 20), (22, 10, 20), (19, 13, 20), (17, 15, 20), (17, 15, 33), (12, 20, 12),
+                              (4, 28, 12), (0, 32, 12)):
+            for mode, name in ((0, "one grid   "), (1, "two launches"), (-1, "library    ")):
+                N.lib().aic_debug_attn_sequential(mode)
+                print(name, end=" ")
+                attn_mix(ns, nl, q_long=qlong)
+        N.lib().aic_debug_attn_sequential(-1)
     if "fp8mix" in what:      # a 32-request lane with long drafts, fp8 cache against bf16
         attn_mix(32, 0, kv8=True)
         for kv8 in (True, False):
