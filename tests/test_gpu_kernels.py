@@ -812,6 +812,41 @@ def test_verify_attention_many_long_drafts_in_a_lane(n_long, kv):
         assert torch.equal(outs[l], want), l
 
 
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_verify_attention_mixed_call_forms_agree(seed):
+    """Lane- and batch-sized mixes of short requests and long drafts (anything from one long draft to all of them, on both
+    sides of the point where the one-grid form runs out of room): the one-grid form, the two-launch form and the library's
+    choice between them give the same attention as the generic path."""
+    from arcticinference_amd import _native as N
+    rng = np.random.RandomState(100 + seed)
+    B = [32, 64, 32, 24, 64, 32, 48, 32][seed]
+    Hkv = [8, 8, 8, 8, 2, 1, 8, 4][seed]
+    G, D, bs = 4, 128, 16
+    Hq = Hkv * G
+    n_long = int(rng.randint(1, B))
+    q_lens = [int(x) for x in rng.randint(9, 34, size=n_long)] + [int(x) for x in rng.choice([1, 1, 2, 4, 7, 8], size=B - n_long)]
+    rng.shuffle(q_lens)
+    ctxs = [int(x) for x in rng.randint(300, 1400, size=B)]
+    max_blocks = max((c + bs - 1) // bs for c in ctxs)
+    nb = B * max_blocks
+    bt = torch.randperm(nb).view(B, max_blocks).to(torch.int32).to(DEV)
+    torch.manual_seed(seed)
+    kc = torch.randn(nb, bs, Hkv, D, device=DEV, dtype=torch.bfloat16)
+    vc = torch.randn(nb, bs, Hkv, D, device=DEV, dtype=torch.bfloat16)
+    q = torch.randn(sum(q_lens), Hq, D, device=DEV, dtype=torch.bfloat16)
+    qsl = torch.tensor(np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32), device=DEV)
+    seq = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
+    run = lambda **kw: _ops().verify_attention(q, kc, vc, bt, seq, qsl, max(q_lens), max(ctxs), D ** -0.5, **kw).float()
+    generic = run()
+    try:
+        for mode in (0, 1, -1):
+            N.check(N.lib().aic_debug_attn_sequential(mode))
+            got = run(q_lens_host=q_lens)
+            assert torch.allclose(got, generic, atol=1e-3, rtol=2 ** -7), (seed, B, Hkv, n_long, mode, float((got - generic).abs().max()))
+    finally:
+        N.check(N.lib().aic_debug_attn_sequential(-1))
+
+
 @pytest.mark.parametrize("Hkv", [8, 1])
 def test_verify_attention_long_draft_split_counts(Hkv):
     """The long-draft part of a one-grid call takes 2-32 token-range splits by the load of the call (a rank of SP = 8 sees
