@@ -79,10 +79,11 @@ def parse_args():
                     help="2: the live requests form two lanes of B/2 whose engine steps are interleaved — one lane's host "
                          "chain (tree update, suffix proposal, index build) runs while the GPU attends for the other; a "
                          "round still advances every request by one step.  1: every request in one engine step per round "
-                         "(host chain and GPU alternate).  0 (default): 2 on one GPU, 1 under SP, where a rank's launches are small "
-                         "and a second lane mostly adds their fixed costs (measured r02, ms per round, 1 / 2 "
-                         "lanes: one GPU 6.76 / 6.43; rehearsed SP 2: 4.02 / 3.86, SP 4: 2.72 / 2.64, SP 8: 2.10 / 2.19; the rehearsal has "
-                         "no collectives, a second lane doubles them on a real group)")
+                         "(host chain and GPU alternate).  0 (default): 2 up to SP = 4, 1 at SP = 8, where a rank's launches are small "
+                         "and a second lane mostly adds their fixed costs (measured, ms per round, 1 / 2 lanes; r02: one GPU "
+                         "6.76 / 6.43, rehearsed SP 2: 4.02 / 3.86, SP 4: 2.72 / 2.64, SP 8: 2.10 / 2.19; r03, same box: SP 4: "
+                         "2.76 / 2.66, SP 8 three pairs: 2.16 / 2.20, 2.03 / 2.15, 2.21 / 2.38; decode-size steps run in shift "
+                         "mode, i.e. without collectives inside attention, so a second lane adds none there)")
     ap.add_argument("--draft-model-per-request", action="store_true",
                     help="extension: requests that suffix decoding did not take still get the draft model's proposal in "
                          "steps where it took others (the reference gives the whole batch none, model_runner.py:616-618)")
@@ -422,7 +423,7 @@ def main():
             replaced[0] += 1
 
     sp_ways = world if world > 1 else max(args.rehearse_sp, 1)
-    n_lanes = args.lanes if args.lanes > 0 else (2 if sp_ways == 1 else 1)
+    n_lanes = args.lanes if args.lanes > 0 else (2 if sp_ways <= 4 else 1)
     n_lanes = max(1, min(n_lanes, B))
     lane_slots = [list(range(l, B, n_lanes)) for l in range(n_lanes)]
     pending = [None] * n_lanes
