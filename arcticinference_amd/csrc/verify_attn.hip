@@ -1152,7 +1152,8 @@ verify_attn_pair_kernel(AttnParams PS, AttnParams PL, int n_long_wg, int n_long_
 // (Merging inside the attention launch instead — tickets, last wave to arrive reads the slots back — was built and
 // measured: no faster for short-only calls, 20-35 us slower with long drafts; profiles/r02_in_launch_merge_experiment.txt.
 // r03: requesting the first four slots' values together with the {max, sum} pairs — one memory round trip per row instead
-// of two — left the launch at 4.85 us (rocprofv3, bench): its time is dispatch and drain of 768 one-wave rows, not latency.)
+// of two — left the launch at 4.85 us (rocprofv3, bench); two to four rows per wave with every phase issued for all of them
+// (a grid of about one workgroup per CU) took 5.2 / 9.8 / 11.2 us: one row per wave it stays.)
 template <int D>
 __global__ void __launch_bounds__(256)
 verify_attn_combine_kernel(const float* __restrict__ ws_o, const float* __restrict__ ws_ml, int n_parts, int total_rows,
