@@ -253,6 +253,12 @@ if __name__ == "__main__":
                 print(f"fp8 layout hpw={hpw} splits={sp}: ", end="")
                 attn_mix(B, 0, kv8=True)
         N.lib().aic_debug_attn_layout(0, 0)
+    if "longctx" in what:     # the long-draft body alone over the context length: fixed cost and slope per 32-token tile
+        for B in (16, 1):
+            for ctx in (128, 512, 1024, 2048, 4096):
+                attn(B=B, ctx=ctx, qlen=33, split=True)
+        for ctx in (128, 1024, 4096):
+            attn(B=16, ctx=ctx, qlen=12, split=True)
     if "manylong" in what:    # a 32-request lane in which suffix decoding hit for many requests (one-grid form out of room)
         for ns, nl, qlong in ((31, 1, 33), (28, 4, 20), (25, 7, 20), (22, 10, 20), (19, 13, 20), (17, 15, 20), (17, 15, 33), (12, 20, 12),
                               (4, 28, 12), (0, 32, 12)):
