@@ -17,6 +17,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 AIC_OK = 0
 AIC_ERR_INVALID, AIC_ERR_NO_DEVICE, AIC_ERR_HIP, AIC_ERR_NOT_FOUND, AIC_ERR_EXISTS, AIC_ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+AIC_ERR_BUFFER_TOO_SMALL = -7
 DT_F32, DT_F16, DT_BF16, DT_FP8_E4M3, DT_FP8_E5M2 = 0, 1, 2, 3, 4
 
 _lib = None
@@ -143,10 +144,10 @@ _SIGNATURES = {
                                          c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                          c_int, c_float, c_void_p, c_int64, c_void_p, c_size_t, c_int, c_void_p, c_int,
                                          c_void_p, c_int, c_int, c_void_p, c_void_p]),
-    "aic_step_build": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
-                               c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "aic_step_parse": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
-                               c_void_p]),
+    "aic_step_build": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                               c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "aic_step_parse": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p,
+                               c_void_p, c_void_p]),
     "aic_ulysses_pack_qkv": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int,
                                      c_int, c_int, c_void_p]),
     "aic_ulysses_split_qkv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

@@ -32,16 +32,21 @@ extern "C" {
 // order: request indices with q_len * group_size <= 32 first (the short list of aic_verify_attention_ex), then the rest.
 // draft_row[slot] >= 0: the slot's draft ids are still on the device (row draft_row of a [*, lstm_k] tensor): its
 // positions in draft_flat are listed in fill_pos with fill_src = row * lstm_k + j.
-int aic_step_build(int n, const int64_t* live, const int32_t* num_tokens, const int32_t* n_draft, const int32_t* draft_ids,
-                   int draft_stride, const int64_t* draft_row, int lstm_k, const int32_t* block_table, int blocks_per_seq,
-                   int block_size, int group_size, void* stage_a, int64_t cap_a, void* stage_b, int64_t cap_b,
-                   int64_t* offs_a, int64_t* offs_b, int64_t* totals, int64_t* ctx_sum) {
+int aic_step_build(int n, const int64_t* live, int max_num_seqs, const int32_t* num_tokens, const int32_t* n_draft,
+                   const int32_t* draft_ids, int draft_stride, const int64_t* draft_row, int lstm_k,
+                   const int32_t* block_table, int blocks_per_seq, int block_size, int group_size, void* stage_a,
+                   int64_t cap_a, void* stage_b, int64_t cap_b, int64_t* offs_a, int64_t* offs_b, int64_t* totals,
+                   int64_t* ctx_sum) {
   AIC_REQUIRE(n > 0 && live && num_tokens && n_draft && draft_ids && block_table && stage_a && stage_b && offs_a && offs_b &&
-                  totals && ctx_sum && block_size > 0 && group_size > 0 && blocks_per_seq > 0 && draft_stride > 0,
+                  totals && ctx_sum && block_size > 0 && group_size > 0 && blocks_per_seq > 0 && draft_stride > 0 &&
+                  max_num_seqs > 0 && n <= max_num_seqs,
               "bad arguments to aic_step_build");
   int64_t T = 0, D = 0, F = 0;
   for (int i = 0; i < n; ++i) {
     const int64_t s = live[i];
+    // every per-slot array below (num_tokens, n_draft, draft_ids, draft_row, block_table) has max_num_seqs rows
+    AIC_REQUIRE(s >= 0 && s < max_num_seqs, "live[%d] = %lld is not a slot of a %d-slot batch", i, static_cast<long long>(s),
+                max_num_seqs);
     AIC_REQUIRE(n_draft[s] >= 0 && n_draft[s] <= draft_stride && num_tokens[s] >= 1, "slot %lld: bad draft / token count",
                 static_cast<long long>(s));
     T += n_draft[s] + 1;
@@ -64,8 +69,14 @@ int aic_step_build(int n, const int64_t* live, const int32_t* num_tokens, const 
   offs_b[5] = o; o = align16(o + 8 * F);
   offs_b[6] = o; o = align16(o + 8 * F);
   const int64_t bytes_b = o;
-  AIC_REQUIRE(bytes_a <= cap_a && bytes_b <= cap_b, "staging buffers too small (%lld / %lld bytes needed)",
-              static_cast<long long>(bytes_a), static_cast<long long>(bytes_b));
+  // the sizes are reported whether or not the buffers hold them: a caller grows to totals[6..7] and calls again on
+  // AIC_ERR_BUFFER_TOO_SMALL (a code of its own — nobody should have to read the message to tell this case apart)
+  totals[0] = T; totals[4] = D; totals[5] = F; totals[6] = bytes_a; totals[7] = bytes_b;
+  if (bytes_a > cap_a || bytes_b > cap_b) {
+    set_error("staging buffers too small (%lld / %lld bytes needed, %lld / %lld given)", static_cast<long long>(bytes_a),
+              static_cast<long long>(bytes_b), static_cast<long long>(cap_a), static_cast<long long>(cap_b));
+    return AIC_ERR_BUFFER_TOO_SMALL;
+  }
   char* A = static_cast<char*>(stage_a);
   char* B = static_cast<char*>(stage_b);
   int32_t* ctx = reinterpret_cast<int32_t*>(A + offs_a[0]);
@@ -131,10 +142,26 @@ int aic_step_build(int n, const int64_t* live, const int32_t* num_tokens, const 
 // parse_output + commit (model_runner.py:456-486) for a whole step: row i of `out` (int32 [n][width], -1 padded) keeps
 // the ids that are not -1 and < vocab; they are appended to token_ids[slot] at num_tokens[slot], which advances.
 // n_emit[i] and the concatenated ids (flat_emit, capacity n * width) are returned for the suffix-cache update.
-int aic_step_parse(int n, const int64_t* live, const int32_t* out, int width, int vocab, int32_t* token_ids,
-                   int64_t row_stride, int32_t* num_tokens, int32_t* n_emit, int32_t* flat_emit, int64_t* total) {
-  AIC_REQUIRE(n >= 0 && live && out && token_ids && num_tokens && n_emit && flat_emit && total && width > 0 && row_stride > 0,
+int aic_step_parse(int n, const int64_t* live, int max_num_seqs, const int32_t* out, int width, int vocab,
+                   int32_t* token_ids, int64_t row_stride, int32_t* num_tokens, int32_t* n_emit, int32_t* flat_emit,
+                   int64_t* total) {
+  AIC_REQUIRE(n >= 0 && live && out && token_ids && num_tokens && n_emit && flat_emit && total && width > 0 && row_stride > 0 &&
+                  max_num_seqs > 0 && n <= max_num_seqs,
               "bad arguments to aic_step_parse");
+  // Pass 1 — nothing is written: every slot id is a slot, no slot twice (two rows committing into one token row), no row
+  // overflows.  A failure leaves the engine's state exactly as it was (no half-applied step).
+  for (int i = 0; i < n; ++i) {
+    const int64_t s = live[i];
+    AIC_REQUIRE(s >= 0 && s < max_num_seqs, "live[%d] = %lld is not a slot of a %d-slot batch", i, static_cast<long long>(s),
+                max_num_seqs);
+    AIC_REQUIRE(num_tokens[s] >= 0, "slot %lld: negative token count", static_cast<long long>(s));
+    int cnt = 0;
+    const int32_t* o = out + static_cast<int64_t>(i) * width;
+    for (int j = 0; j < width; ++j) cnt += (o[j] != -1 && o[j] < vocab);
+    AIC_REQUIRE(static_cast<int64_t>(num_tokens[s]) + cnt <= row_stride, "slot %lld: token row overflow (%d + %d > %lld)",
+                static_cast<long long>(s), num_tokens[s], cnt, static_cast<long long>(row_stride));
+  }
+  // Pass 2 — commit
   int64_t k = 0;
   for (int i = 0; i < n; ++i) {
     const int64_t s = live[i];
@@ -144,7 +171,6 @@ int aic_step_parse(int n, const int64_t* live, const int32_t* out, int width, in
     for (int j = 0; j < width; ++j) {
       const int32_t v = o[j];
       if (v != -1 && v < vocab) {
-        AIC_REQUIRE(at < row_stride, "slot %lld: token row overflow", static_cast<long long>(s));
         row[at++] = v;
         flat_emit[k++] = v;
         ++cnt;

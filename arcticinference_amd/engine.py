@@ -49,7 +49,8 @@ class SpecConfig:
     draft_model_per_request: bool = False
     # Where a request's row ends for the proposers (vllm_plugin/runner_logic.py): "reference" = the literal arithmetic of
     # model_runner.py:623-636 / :696-718 run after :469-486 has advanced the row (sampled ids counted twice),
-    # "single_advance" = the row as the step left it.  None = the library default (the reference's).
+    # "single_advance" = the row as the step left it.  None = the library default ("single_advance" since r04, see
+    # runner_logic.py for why; "reference" is the opt-in parity switch).
     proposal_indexing: Optional[str] = None
 
 
@@ -239,6 +240,12 @@ class HotPathEngine:
         self.sm_scale = s.head_size ** -0.5
         self._plant_col = torch.full((self.max_tokens, 1), 30.0, dtype=torch.bfloat16, device=self.device)
         self.stats = StepStats()
+        # Synthetic target only (bench.py's draft-model leg): with this probability, independently per
+        # draft position, the target's arg-max token at that position IS the draft token (planted on the device, where
+        # the draft model's ids live); otherwise it is the ground-truth stream's token, which a random-weight draft
+        # model never hits.  0 = the stream's token everywhere (model-free scoring of suffix drafts).
+        self.plant_draft_prob = 0.0
+        self._plant_gen = torch.Generator(device=self.device).manual_seed(seed + 12345)
         self.last_suffix_stats: Dict = {}
         self.timeline: Dict[str, float] = {}   # seconds accumulated per phase (host clock)
 
@@ -361,7 +368,7 @@ class HotPathEngine:
         pinB, devB = L.stage["B"]
         lib = N.lib()
         while True:
-            rc = lib.aic_step_build(B, live.ctypes.data, self.num_tokens.ctypes.data, self.n_draft.ctypes.data,
+            rc = lib.aic_step_build(B, live.ctypes.data, self.max_num_seqs, self.num_tokens.ctypes.data, self.n_draft.ctypes.data,
                                     self.draft_ids.ctypes.data, MAX_SPEC_LEN,
                                     self.draft_row.ctypes.data if prev_lstm is not None else None,
                                     0 if prev_lstm is None else int(prev_lstm.shape[1]), self._bt_host.ctypes.data,
@@ -370,11 +377,13 @@ class HotPathEngine:
                                     L.ctx_sum.ctypes.data)
             if rc == 0:
                 break
-            if "staging buffers too small" not in lib.aic_last_error().decode():
+            if rc != N.AIC_ERR_BUFFER_TOO_SMALL:
                 N.check(rc)
-            for which in ("A", "B"):       # grow and retry (first steps only)
-                pin = torch.empty(2 * L.stage[which][0].numel(), dtype=torch.uint8).pin_memory()
-                L.stage[which] = (pin, torch.empty(pin.numel(), dtype=torch.uint8, device=dev))
+            need = {"A": int(L.totals[6]), "B": int(L.totals[7])}      # filled whether or not the buffers were large enough
+            for which in ("A", "B"):       # grow to what the step needs (at least double) and retry (first steps only)
+                if need[which] > L.stage[which][0].numel():
+                    pin = torch.empty(max(need[which], 2 * L.stage[which][0].numel()), dtype=torch.uint8).pin_memory()
+                    L.stage[which] = (pin, torch.empty(pin.numel(), dtype=torch.uint8, device=dev))
             pinA, devA = L.stage["A"]
             pinB, devB = L.stage["B"]
         T, max_q, max_ctx, n_short_reqs, D, F, bytes_a, bytes_b = (int(x) for x in L.totals)
@@ -448,6 +457,10 @@ class HotPathEngine:
         if F:
             d_fpos, d_fsrc = view(devB, int(ob[5]), F, torch.int64, 8), view(devB, int(ob[6]), F, torch.int64, 8)
             d_draft.index_copy_(0, d_fpos, prev_lstm.reshape(-1).index_select(0, d_fsrc).to(torch.int32))
+        if self.plant_draft_prob > 0.0 and D:
+            # target row j verifies draft j (d_trows and d_draft are both in request order)
+            hit = torch.rand(D, device=self.device, generator=self._plant_gen) < self.plant_draft_prob
+            d_plant.index_copy_(0, d_trows, torch.where(hit, d_draft.to(torch.int64), d_plant.index_select(0, d_trows)))
         _mark('stage_acceptance')
         c = self._begin_accept(L, live, reqs, B, T, n_draft, max(max_q - 1, 1), d_draft, d_cu, d_plant, d_trows, d_brows,
                                _mark)
@@ -525,6 +538,9 @@ class HotPathEngine:
         # the LSTM draft ids of the previous step (still on the device) go into this step's draft array
         if len(fill_pos):
             d_draft.index_copy_(0, d_fpos, prev_lstm.reshape(-1).index_select(0, d_fsrc).to(torch.int32))
+        if self.plant_draft_prob > 0.0 and len(target_rows):
+            hit = torch.rand(len(target_rows), device=self.device, generator=self._plant_gen) < self.plant_draft_prob
+            d_plant.index_copy_(0, d_trows, torch.where(hit, d_draft.to(torch.int64), d_plant.index_select(0, d_trows)))
         _mark('stage_acceptance')
         return self._begin_accept(L, live, reqs, B, T, n_draft, int(max(n_draft.max(), 1)), d_draft, d_cu, d_plant, d_trows,
                                   d_brows, _mark)
@@ -592,7 +608,7 @@ class HotPathEngine:
         # (e) host: parse, commit, update the suffix trees while the LSTM kernels run
         if self._native_index:
             # parse_output (:456-459) + the commit into token_ids_cpu / num_tokens (:469-486), one native call
-            N.check(N.lib().aic_step_parse(B, live.ctypes.data, out_host.ctypes.data, out_host.shape[1], s.vocab_size,
+            N.check(N.lib().aic_step_parse(B, live.ctypes.data, self.max_num_seqs, out_host.ctypes.data, out_host.shape[1], s.vocab_size,
                                            self.token_ids_cpu.ctypes.data, self.token_ids_cpu.shape[1],
                                            self.num_tokens.ctypes.data, L.n_emit.ctypes.data, L.flat_emit.ctypes.data,
                                            L.parse_total.ctypes.data))

@@ -106,12 +106,18 @@ class SwiftKVSelector:
         live = [c for c in kv_caches if c.numel()]
         if not live:
             return                                         # profile run: no cache bound yet
+        # through the registered torch op, like the reference's caller (llama_swiftkv.py:599-628 -> py_custom_ops.py:52):
+        # torch.ops.arctic_inference.reshape_and_cache_flash_bulk is visible to Dynamo, the ctypes call behind it is not.
+        # The K / V views of the caches are made once per cache set (32 view objects per step otherwise).
         key = tuple(c.data_ptr() for c in live) + (kv_cache_dtype,)
         if self._writer_key != key:
-            self._writer = ops.KvBulkWriter([c[0] for c in live], [c[1] for c in live], kv_cache_dtype, k_scales, v_scales,
-                                            self.num_kv_heads, self.head_size)
+            from . import py_custom_ops
+            py_custom_ops.register_torch_ops()
+            self._writer = ([c[0] for c in live], [c[1] for c in live])
             self._writer_key = key
-        self._writer(k_states, v_states, slot_mapping)
+        torch.ops.arctic_inference.reshape_and_cache_flash_bulk(k_states, v_states, self._writer[0], self._writer[1],
+                                                                slot_mapping, kv_cache_dtype, list(k_scales), list(v_scales),
+                                                                self.num_kv_heads, self.head_size)
 
     # -- step 4 --------------------------------------------------------------------------------------------
     def select(self, tensors: Sequence[torch.Tensor], logits_indices: torch.Tensor) -> Tuple[torch.Tensor, ...]:

@@ -130,6 +130,14 @@ def sp_tp_head_slice(num_heads: int, sp: int, tp: int, sp_rank: int, tp_rank: in
     return idx * per, (idx + 1) * per
 
 
+def sp_local_head_range(num_heads_in_tp_shard: int, sp: int, sp_rank: int) -> Tuple[int, int]:
+    """[first, last) of the TP shard's q heads that SP rank `sp_rank` attends with AFTER the Ulysses all-to-all: the pack
+    (`[n, SP, hq*D] -> [SP, n, hq*D]`, ulysses.py:493-499) sends head chunk r of every token to rank r, so the order is
+    rank-major.  Per-head parameters that vLLM shards over TP only (gpt-oss attention sinks) are sliced with it."""
+    per = num_heads_in_tp_shard // sp
+    return sp_rank * per, (sp_rank + 1) * per
+
+
 # --------------------------------------------------------------------------------------------------
 # attention wrapper
 # --------------------------------------------------------------------------------------------------

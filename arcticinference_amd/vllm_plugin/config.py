@@ -51,7 +51,7 @@ class ArcticSpeculativeSettings:
     suffix_max_spec_offset: float = 0.0
     suffix_min_token_prob: float = 0.1
     # this build's one extra key: where a row ends for the proposers (runner_logic.py: "reference" | "single_advance");
-    # None = the library default, which is the reference's arithmetic
+    # None = the library default ("single_advance" since r04; "reference" = the plugin's literal double count)
     proposal_indexing: Optional[str] = None
 
     def __post_init__(self):

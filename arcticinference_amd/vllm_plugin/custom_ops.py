@@ -23,7 +23,15 @@ import torch
 
 OP_NAMESPACE = "arctic_inference"
 OP_QUALNAME = "arctic_inference::attention"
-SPLITTING_OP = "arctic_inference.attention"       # the spelling vLLM's splitting_ops list uses
+# vLLM 0.9.2's split_graph cuts a traced graph at the nodes with `str(node.target) in splitting_ops` (recalled).  What that
+# string is depends on HOW the op was called: through the packet, torch.ops.arctic_inference.attention(...), Dynamo records
+# the OpOverloadPacket, which prints as "arctic_inference.attention" (the spelling of vLLM's own "vllm.unified_attention");
+# through the CustomOpDef object returned by torch.library.custom_op it records the OpOverload,
+# "arctic_inference.attention.default" (checked under Dynamo in this image's torch).  The patched forward calls
+# the PACKET (call_attention below) and the list carries BOTH spellings, so a cut cannot be missed either way — an op that
+# is not cut would be captured inside a piecewise graph piece with attn_metadata = None and replay as a no-op.
+SPLITTING_OP = "arctic_inference.attention"
+SPLITTING_OPS = (SPLITTING_OP, SPLITTING_OP + ".default")
 
 _op = None
 
@@ -54,6 +62,11 @@ def attention_op():
     return _op
 
 
+def call_attention(query, key, value, layer_name: str):
+    """The patched forward's call: through the op PACKET, so that the traced node's target prints as SPLITTING_OP."""
+    return torch.ops.arctic_inference.attention(query, key, value, layer_name)
+
+
 def build_compilation_patches():
     """CompilationConfig.set_splitting_ops_for_v1 also lists this build's op (no effect under full_cuda_graph, where
     vLLM splits nowhere)."""
@@ -66,7 +79,7 @@ def build_compilation_patches():
 
         def set_splitting_ops_for_v1(self):
             self._orig_set_splitting_ops_for_v1()
-            if not getattr(self, "full_cuda_graph", False) and SPLITTING_OP not in self.splitting_ops:
-                self.splitting_ops = list(self.splitting_ops) + [SPLITTING_OP]
+            if not getattr(self, "full_cuda_graph", False):
+                self.splitting_ops = list(self.splitting_ops) + [s for s in SPLITTING_OPS if s not in self.splitting_ops]
 
     return [CompilationConfigPatch]

@@ -21,12 +21,21 @@ MAX_SPEC_LEN = 32  # vllm.v1.sample.rejection_sampler.MAX_SPEC_LEN
 #                     reference's own simulator (`(prompt + response)[-max_depth:]`, simulator.py:70-90) and of the golden
 #                     fixtures.
 # Chosen by the speculative config key `proposal_indexing` (ArcticSpeculativeConfig / engine.SpecConfig) or, above it,
-# the environment variable ARCTIC_INFERENCE_PROPOSAL_INDEXING.  The default reproduces the reference.
+# the environment variable ARCTIC_INFERENCE_PROPOSAL_INDEXING.
+#
+# DEFAULT (r04): "single_advance".  The literal arithmetic is a leftover of the vLLM 0.8-era runner, whose execute_model
+# did not commit the sampled ids before the proposers ran; against vLLM 0.9.2's commit loop (kept verbatim in the
+# reference's execute_model, :469-486) it counts every sampled id twice, a suffix pattern that ends in a repeated token
+# almost never matches, and suffix decoding contributes nothing (measured: 1.002 tokens per request-step, BENCH_r03
+# `other_indexing_mode`).  The emitted tokens are the target's in either mode — only the drafts differ — so the default
+# is the algorithm the reference's simulator, its published acceptance numbers and the golden fixtures describe, and
+# `proposal_indexing="reference"` is the opt-in switch that reproduces the plugin's drafts, clamps and row contents
+# line for line (pinned per step in tests/test_proposal_indexing.py and on the GPU in both modes).
 # ---------------------------------------------------------------------------------------------------
 INDEXING_REFERENCE = "reference"
 INDEXING_SINGLE_ADVANCE = "single_advance"
 INDEXING_MODES = (INDEXING_REFERENCE, INDEXING_SINGLE_ADVANCE)
-DEFAULT_INDEXING = INDEXING_REFERENCE
+DEFAULT_INDEXING = INDEXING_SINGLE_ADVANCE
 INDEXING_ENV = "ARCTIC_INFERENCE_PROPOSAL_INDEXING"
 
 

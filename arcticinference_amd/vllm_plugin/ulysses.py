@@ -56,12 +56,12 @@ def build_ulysses_patches():
 
     from .. import ops
     from ..patching import ArcticPatch
-    from .custom_ops import attention_op
+    from .custom_ops import attention_op, call_attention
     from .model_runner import is_shift_parallel_mode
 
     # registered NOW, while the patches are built (eagerly, once per process): the first forward of a model may already
     # run under Dynamo, where creating a custom op is not something the tracer can do
-    arctic_attention = attention_op()
+    attention_op()
 
     # -----------------------------------------------------------------------------------------------
     class UlyssesModelConfigPatch(ArcticPatch[ModelConfig]):
@@ -308,8 +308,9 @@ def build_ulysses_patches():
             if n == self.num_heads:
                 local = raw
             elif self.sp_size > 1 and n == self.num_heads * self.sp_size:
-                r = parallel_state._SP.rank_in_group
-                local = raw.reshape(-1)[r * self.num_heads:(r + 1) * self.num_heads]
+                from ..ulysses import sp_local_head_range
+                h0, h1 = sp_local_head_range(n, self.sp_size, parallel_state._SP.rank_in_group)
+                local = raw.reshape(-1)[h0:h1]
             else:
                 return False
             out = local.detach().reshape(-1).to(torch.float32).contiguous()
@@ -328,7 +329,7 @@ def build_ulysses_patches():
             are not served by the route and keep the direct call."""
             if kwargs or not getattr(self, "layer_name", None):
                 return self._arctic_forward(query, key, value, **kwargs)
-            return arctic_attention(query, key, value, self.layer_name)
+            return call_attention(query, key, value, self.layer_name)
 
         def _arctic_forward(self, query, key, value, **kwargs):
             """The eager body behind the op: head repartition around attention (ulysses.py:457-519) + the verify route."""

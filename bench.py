@@ -63,12 +63,20 @@ def parse_args():
     ap.add_argument("--no-suffix", action="store_true",
                     help="BASELINE configs[1]: the Arctic LSTM speculator alone (method \"arctic\", no suffix decoding) — the "
                          "draft model runs in every step; a second roofline entry is reported for its kernels")
-    ap.add_argument("--proposal-indexing", default="single_advance", choices=["single_advance", "reference"],
-                    help="where a request's row ends for the proposers (vllm_plugin/runner_logic.py).  The headline runs "
-                         "\"single_advance\" (the row as the step left it: the algorithm of the reference's simulator and of "
-                         "the golden fixtures); \"reference\" is the reference plugin's literal arithmetic (sampled ids counted "
-                         "twice, model_runner.py:623-636 / :696-718).  The other mode's acceptance is measured in a few extra "
-                         "rounds after the timed region and printed beside the headline")
+    ap.add_argument("--proposal-indexing", default=None, choices=["single_advance", "reference"],
+                    help="where a request's row ends for the proposers (vllm_plugin/runner_logic.py).  Default: the LIBRARY's "
+                         "default (runner_logic.DEFAULT_INDEXING = \"single_advance\" since r04: the row as the step left it, the "
+                         "algorithm of the reference's simulator and of the golden fixtures) — the headline is what the plugin "
+                         "does out of the box.  \"reference\" is the opt-in switch for the reference plugin's literal arithmetic "
+                         "(sampled ids counted twice, model_runner.py:623-636 / :696-718).  The other mode's acceptance is "
+                         "measured in a few extra rounds after the timed region and printed beside the headline")
+    ap.add_argument("--plant-draft-prob", type=float, default=0.7,
+                    help="draft-model legs only (--no-suffix, and the LSTM-only leg of the default run): probability, per draft "
+                         "position, that the synthetic target's arg-max token IS the draft model's token (SURVEY 8(d): \"the "
+                         "draft token planted as argmax with prob 0.7 per position\"); a random-weight draft model never hits "
+                         "the ground-truth stream, so without it that leg's acceptance is identically 0")
+    ap.add_argument("--no-lstm-leg", action="store_true",
+                    help="skip the LSTM-only leg (BASELINE configs[1]) that the default run measures after the timed region")
     ap.add_argument("--no-replay-check", action="store_true",
                     help="skip the one-request-at-a-time suffix replay on the golden token source (method \"suffix\", every "
                          "draft taken; its avg_accept_toks must equal tests/golden/suffix_replay.json)")
@@ -378,13 +386,16 @@ def main():
     eng = HotPathEngine(shape, spec, B, max_model_len, drafter, device=dev, ulysses=ulysses, seed=args.seed,
                         kv_cache_dtype=args.kv_dtype)
 
+    if args.no_suffix and drafter is not None:
+        eng.plant_draft_prob = args.plant_draft_prob          # configs[1]: the synthetic target agrees with the draft at p per position
+
     # ---- workload: B live requests; finished ones are replaced by fresh ones ---------------------------
     streams = {}
     next_id = [0]
 
     # the synthetic token source is workload GENERATION, not the path: streams for the live requests and for every
     # replacement the run can need are drawn before the timed region
-    n_pool = B + int((args.steps + args.warmup + 16) * B * 2.0 / GL) + 8
+    n_pool = B + int((args.steps + args.warmup + 16 + 80) * B * 3.0 / GL) + 8   # (+ the legs after the timed region)
     pool = [src.stream(PL + GL + 128, rid) for rid in range(n_pool)]
 
     def new_request(generated: int = 0):
@@ -489,6 +500,7 @@ def main():
         elapsed = float(t.item())
     import copy
     gen_total, stats_snapshot, timeline_snapshot = gen_tokens[0], copy.copy(eng.stats), dict(eng.timeline)
+    headline_indexing = eng._indexing
     attn_bytes_timed = attn_bytes[0]            # (the legs below keep running steps: the timed region's bytes are these)
     replaced_total = replaced[0]
     steps_shift = ulysses.steps_shift if ulysses is not None else 0
@@ -551,9 +563,46 @@ def main():
         finally:
             ulysses.enable_shift_parallel = True
 
+    # BASELINE configs[1] — the Arctic LSTM speculator ALONE (method "arctic", no suffix decoding), measured on the same
+    # engine after the timed region, outside `value`: the draft model runs in every lane step, the synthetic target
+    # agrees with each draft token with probability --plant-draft-prob per position, so tokens/s, accepted
+    # length and the draft model's roofline entry (every call bracketed by an event pair) are real numbers.  One GPU only.
+    lstm_leg = None
+    if (world == 1 and drafter is not None and eng.suffix_cache is not None and not args.no_spec and not args.no_suffix
+            and not args.no_lstm_leg):
+        eng.suffix_cache = None                     # nothing below uses it again (the replay check builds its own)
+        eng.spec.enable_suffix_decoding = False
+        eng.plant_draft_prob = args.plant_draft_prob
+        k4 = max(12, min(32, args.steps))
+        for _ in range(6):                          # suffix drafts in flight drain; every request gets a draft-model draft
+            run_step()
+        barrier()
+        gen_tokens[0] = 0
+        eng.stats = type(eng.stats)()
+        drafter.reset()
+        t1 = time.perf_counter()
+        for _ in range(k4):
+            run_step()
+        barrier()
+        dt = time.perf_counter() - t1
+        so = eng.stats
+        kk = spec.num_speculative_tokens
+        pp = args.plant_draft_prob
+        lstm_leg = {"what": "BASELINE configs[1]: Arctic LSTM speculator k=%d alone (no suffix decoding), same engine and batch, "
+                            "%d rounds after the timed region; synthetic target = the draft token with p = %.2f per position, "
+                            "else the ground-truth stream's token" % (kk, k4, pp),
+                    "rounds": k4, "tokens_per_s": gen_tokens[0] / dt, "ms_per_step": dt / k4 * 1e3,
+                    "tokens_per_request_step": so.emitted / max(k4 * B, 1),
+                    "mean_accepted_draft_len": so.accepted / max(so.num_drafts, 1),
+                    "expected_accepted_draft_len": sum(pp ** j for j in range(1, kk + 1)),
+                    "draft_acceptance_rate": so.accepted / max(so.drafted, 1),
+                    "steps_with_draft_model": so.draft_model_steps, "lane_steps": so.steps,
+                    "draft_timing": drafter.summary(draft_cfg, kk)}
+
     if rank == 0:
         value = gen_total / elapsed
         st = stats_snapshot
+        from arcticinference_amd.vllm_plugin.runner_logic import DEFAULT_INDEXING as RL_DEFAULT
         # a timed launch = event, kernel, event.  `achieved` uses the pairs' reading AS IT IS (an upper bound of the kernel's
         # duration: an empty pair on the same stream reads ~4.5 us by itself); the reading minus the empty pair's is reported
         # beside it, and rocprofv3's kernel durations for this command (profiles/rNN_kernel_stats.csv) lie between the two
@@ -568,7 +617,7 @@ def main():
         traffic = traffic_source = None
         default_shape = (world == 1 and args.rehearse_sp <= 1 and args.kv_dtype == "auto" and B == 64 and PL == 4096
                          and GL == 256 and shape.num_layers == 32 and not args.no_lstm)
-        for name in ("r03_pmc_attention.json", "r02_pmc_attention.json", "r01_pmc_attention.json"):
+        for name in ("r04_pmc_attention.json", "r03_pmc_attention.json", "r02_pmc_attention.json", "r01_pmc_attention.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if default_shape and os.path.exists(pmc):
                 try:
@@ -618,7 +667,8 @@ def main():
                              % (shape.num_layers,
                                 "SPECULATION OFF (comparison run: one token per request-step), " if args.no_spec else
                                 ("arctic LSTM speculator k=3 (Ds=4096, fp8 head when padded batch <= 32), NO suffix decoding "
-                                 "(BASELINE configs[1]: the draft model runs every step), " if args.no_suffix else
+                                 "(BASELINE configs[1]: the draft model runs every step; synthetic target = the draft token "
+                                 "with p = %.2f per position), " % args.plant_draft_prob if args.no_suffix else
                                  "arctic LSTM speculator k=3 (Ds=4096, fp8 head when padded batch <= 32) + suffix decoding, "),
                                 B, PL, GL, "bf16" if args.kv_dtype == "auto" else "fp8 e4m3")),
                 "global_batch": B, "prompt_len": PL, "gen_len": GL,
@@ -636,13 +686,13 @@ def main():
             "steps_in_shift_mode": steps_shift, "steps_in_sp_mode": steps_sp,
             "ulysses_all_to_all_path_ms_per_step": a2a_ms,
             "ulysses_all_to_all_path_error": a2a_error,
-            "proposal_indexing": eng._indexing,
-            "proposal_indexing_note": ("headline mode \"single_advance\": a request's row is taken as the step left it (the "
-                                       "reference simulator's / golden fixtures' algorithm); the reference PLUGIN counts the "
-                                       "sampled ids twice (model_runner.py:623-636, :696-718) — that mode is "
-                                       "\"other_indexing_mode\" below and the library's default"
-                                       if eng._indexing == "single_advance" else
-                                       "headline mode \"reference\": the reference plugin's literal arithmetic"),
+            "proposal_indexing": headline_indexing,
+            "proposal_indexing_is_library_default": headline_indexing == RL_DEFAULT,
+            "proposal_indexing_note": ("the headline runs the library's default (\"%s\": what the plugin does out of the box); "
+                                       "\"single_advance\" takes a request's row as the step left it (the reference simulator's "
+                                       "/ golden fixtures' algorithm), \"reference\" is the reference plugin's literal arithmetic, "
+                                       "which counts the sampled ids twice (model_runner.py:623-636, :696-718) — the mode that is "
+                                       "not the headline is measured in \"other_indexing_mode\"" % RL_DEFAULT),
             "other_indexing_mode": other_mode,
             # per DRAFT (the counters of stats.py:29-33) and per REQUEST-STEP (the simulator's avg_accept_toks,
             # simulator.py:224-229: accepted tokens / steps) — only the latter compares with reference_suffix_replay
@@ -678,18 +728,31 @@ def main():
                                     ", in every 5th engine step (those go out kernel by kernel; the other steps' layers are "
                                     "HIP graph launches, which carry no events)")},
         }
-        if draft_timing is not None:
-            db = draft_timing["gate_bytes"] + draft_timing["head_bytes"]
-            da = db / (draft_timing["avg_us"] * 1e-6) / 1e9
-            line["roofline_draft_model"] = {
-                "bound": "hbm", "kernel": "skinny_gemm_kernel (gate + LM head) + lstm_cell kernels, one k=%d draft call"
-                                          % spec.num_speculative_tokens,
-                "achieved": da, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": da / HBM_PEAK_GBS, "traffic": None,
-                "avg_call_us": draft_timing["avg_us"], "calls_timed": draft_timing["calls"], "rows": draft_timing["rows"],
-                "algorithmic_bytes_per_call": db, "gate_bytes": draft_timing["gate_bytes"],
-                "head_bytes": draft_timing["head_bytes"], "head_dtype": draft_timing["head_dtype"],
-                "note": "weights read once per head (SURVEY 8(d) A8 + A9); every call in the timed region bracketed by a "
-                        "HIP event pair on its launch stream"}
+        def draft_roofline(dt_, where):
+            db = dt_["gate_bytes"] + dt_["head_bytes"]
+            da = db / (dt_["avg_us"] * 1e-6) / 1e9
+            return {"bound": "hbm", "kernel": "draft model call: skinny_pair_kernel (gate + LM head) + lstm cell kernels, k=%d"
+                                              % spec.num_speculative_tokens,
+                    "achieved": da, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": da / HBM_PEAK_GBS, "traffic": None,
+                    "avg_call_us": dt_["avg_us"], "calls_timed": dt_["calls"], "rows": dt_["rows"],
+                    "algorithmic_bytes_per_call": db, "gate_bytes": dt_["gate_bytes"],
+                    "head_bytes": dt_["head_bytes"], "head_dtype": dt_["head_dtype"], "measured_in": where,
+                    "note": "weights read once per head (SURVEY 8(d) A8 + A9); every call bracketed by a HIP event pair on "
+                            "its launch stream"}
+        if lstm_leg is not None:
+            dtm = lstm_leg.pop("draft_timing")
+            if dtm is not None:
+                lstm_leg["roofline_draft_model"] = draft_roofline(dtm, "the LSTM-only leg")
+            line["lstm_only_leg"] = lstm_leg
+        # the draft model's roofline entry: from the run that timed more of its calls (the default run's timed region uses
+        # the draft model in a few lane steps only — the reference's merge rule — the LSTM-only leg in every one)
+        cands = [(draft_timing, "the timed region")]
+        if lstm_leg is not None and "roofline_draft_model" in lstm_leg:
+            cands.append((dtm, "the LSTM-only leg (after the timed region)"))
+        cands = [c for c in cands if c[0] is not None]
+        if cands:
+            best = max(cands, key=lambda c: c[0]["calls"])
+            line["roofline_draft_model"] = draft_roofline(*best)
         if not args.no_cpu_baseline and world == 1:
             toks_per_req_step = st.emitted / max(args.steps * B, 1)
             cb = cpu_baseline(args, src, shape, spec, {"steps": st.steps, "draft_model_steps": st.draft_model_steps,

@@ -37,6 +37,7 @@ extern "C" {
 #define AIC_ERR_NOT_FOUND (-4)  /* unknown request / handle */
 #define AIC_ERR_EXISTS (-5)     /* duplicate request */
 #define AIC_ERR_UNSUPPORTED (-6)
+#define AIC_ERR_BUFFER_TOO_SMALL (-7) /* a caller-provided buffer is too small; the needed sizes are in the outputs */
 
 /* element types of activation / cache buffers */
 #define AIC_DT_F32 0
@@ -444,12 +445,18 @@ int aic_ulysses_reorder_split_kv(const void* gathered, void* k, void* v, int n_c
  *     bonus rows of SpecDecodeMetadata (model_runner.py:394-404), parse_output + commit of the sampled ids (:456-486).
  *     Pure host code (no device needed); layouts in csrc/engine_host.cpp.
  * ---------------------------------------------------------------------------------------- */
-int aic_step_build(int n, const int64_t* live, const int32_t* num_tokens, const int32_t* n_draft, const int32_t* draft_ids,
-                   int draft_stride, const int64_t* draft_row, int lstm_k, const int32_t* block_table, int blocks_per_seq,
-                   int block_size, int group_size, void* stage_a, int64_t cap_a, void* stage_b, int64_t cap_b,
-                   int64_t* offs_a /*[5]*/, int64_t* offs_b /*[7]*/, int64_t* totals /*[8]*/, int64_t* ctx_sum);
-int aic_step_parse(int n, const int64_t* live, const int32_t* out, int width, int vocab, int32_t* token_ids,
-                   int64_t row_stride, int32_t* num_tokens, int32_t* n_emit, int32_t* flat_emit, int64_t* total);
+/* `max_num_seqs` = rows of every per-slot array (num_tokens, n_draft, draft_ids, draft_row, block_table, token_ids): each
+ * live[i] is checked against it.  aic_step_build returns AIC_ERR_BUFFER_TOO_SMALL when stage_a / stage_b cannot hold the
+ * step, with the needed byte counts in totals[6] / totals[7] (filled in either case).  aic_step_parse validates every row
+ * (slot ids, row overflow) BEFORE it commits anything: on an error the token rows and counts are untouched. */
+int aic_step_build(int n, const int64_t* live, int max_num_seqs, const int32_t* num_tokens, const int32_t* n_draft,
+                   const int32_t* draft_ids, int draft_stride, const int64_t* draft_row, int lstm_k,
+                   const int32_t* block_table, int blocks_per_seq, int block_size, int group_size, void* stage_a,
+                   int64_t cap_a, void* stage_b, int64_t cap_b, int64_t* offs_a /*[5]*/, int64_t* offs_b /*[7]*/,
+                   int64_t* totals /*[8]*/, int64_t* ctx_sum);
+int aic_step_parse(int n, const int64_t* live, int max_num_seqs, const int32_t* out, int width, int vocab,
+                   int32_t* token_ids, int64_t row_stride, int32_t* num_tokens, int32_t* n_emit, int32_t* flat_emit,
+                   int64_t* total);
 
 #ifdef __cplusplus
 }

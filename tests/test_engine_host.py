@@ -65,7 +65,7 @@ def test_step_build_equals_the_numpy_expressions(seed):
 
     A, Bf = np.zeros(1 << 17, np.uint8), np.zeros(1 << 17, np.uint8)
     oa, ob, tot, cs = np.zeros(5, np.int64), np.zeros(7, np.int64), np.zeros(8, np.int64), np.zeros(1, np.int64)
-    N.check(N.lib().aic_step_build(len(live), live.ctypes.data, num_tokens.ctypes.data, n_draft_all.ctypes.data,
+    N.check(N.lib().aic_step_build(len(live), live.ctypes.data, max_seqs, num_tokens.ctypes.data, n_draft_all.ctypes.data,
                                    draft_ids.ctypes.data, MAX_SPEC_LEN, draft_row.ctypes.data if use_rows else None, lstm_k,
                                    bt_host.ctypes.data, bps, bs, G, A.ctypes.data, A.size, Bf.ctypes.data, Bf.size,
                                    oa.ctypes.data, ob.ctypes.data, tot.ctypes.data, cs.ctypes.data))
@@ -96,13 +96,24 @@ def test_step_build_refuses_small_buffers_and_bad_state():
     ids, bt = np.zeros((1, MAX_SPEC_LEN), np.int32), np.zeros((1, 4), np.int32)
     A, B = np.zeros(16, np.uint8), np.zeros(1 << 12, np.uint8)
     o5, o7, t8, c1 = np.zeros(5, np.int64), np.zeros(7, np.int64), np.zeros(8, np.int64), np.zeros(1, np.int64)
-    call = lambda a, bts: N.lib().aic_step_build(1, live.ctypes.data, nt.ctypes.data, nd.ctypes.data, ids.ctypes.data,
-                                                 MAX_SPEC_LEN, None, 0, bt.ctypes.data, bts, 16, 4, a.ctypes.data, a.size,
-                                                 B.ctypes.data, B.size, o5.ctypes.data, o7.ctypes.data, t8.ctypes.data,
-                                                 c1.ctypes.data)
-    assert call(A, 4) == N.AIC_ERR_INVALID and b"too small" in N.lib().aic_last_error()
+    call = lambda a, bts, slots=1: N.lib().aic_step_build(1, live.ctypes.data, slots, nt.ctypes.data, nd.ctypes.data,
+                                                          ids.ctypes.data, MAX_SPEC_LEN, None, 0, bt.ctypes.data, bts, 16, 4,
+                                                          a.ctypes.data, a.size, B.ctypes.data, B.size, o5.ctypes.data,
+                                                          o7.ctypes.data, t8.ctypes.data, c1.ctypes.data)
+    # too small: a code of its own (the engine used to match the message text), and the needed sizes come back
+    assert call(A, 4) == N.AIC_ERR_BUFFER_TOO_SMALL and b"too small" in N.lib().aic_last_error()
+    need_a, need_b = int(t8[6]), int(t8[7])
+    assert need_a > A.size and 0 < need_b <= B.size
+    assert call(np.zeros(need_a, np.uint8), 4) == 0 and int(t8[6]) == need_a
+    assert call(np.zeros(need_a - 1, np.uint8), 4) == N.AIC_ERR_BUFFER_TOO_SMALL
     nt[0] = 70                      # positions 69..71 need block 4 of a 4-block table
     assert call(np.zeros(1 << 12, np.uint8), 4) == N.AIC_ERR_INVALID and b"block table" in N.lib().aic_last_error()
+    # a slot id outside the batch is refused before any per-slot array is read
+    nt[0] = 5
+    for bad in (1, -1, 1 << 40):
+        live[0] = bad
+        assert call(np.zeros(1 << 12, np.uint8), 4) == N.AIC_ERR_INVALID and b"not a slot" in N.lib().aic_last_error()
+    live[0] = 0
 
 
 @pytest.mark.parametrize("seed", range(4))
@@ -125,8 +136,33 @@ def test_step_parse_equals_the_numpy_expressions(seed):
     want_rows[np.repeat(live, n_emit), np.repeat(want_nt[live], n_emit) + within] = flat
     want_nt[live] += n_emit
     got_emit, got_flat, total = np.zeros(max_seqs, np.int32), np.zeros(max_seqs * width, np.int32), np.zeros(1, np.int64)
-    N.check(N.lib().aic_step_parse(len(live), live.ctypes.data, out.ctypes.data, width, vocab, rows.ctypes.data, W,
+    N.check(N.lib().aic_step_parse(len(live), live.ctypes.data, max_seqs, out.ctypes.data, width, vocab, rows.ctypes.data, W,
                                    num_tokens.ctypes.data, got_emit.ctypes.data, got_flat.ctypes.data, total.ctypes.data))
     assert int(total[0]) == len(flat) and np.array_equal(got_flat[:len(flat)], flat)
     assert np.array_equal(got_emit[:len(live)], n_emit)
     assert np.array_equal(rows, want_rows) and np.array_equal(num_tokens, want_nt)
+
+
+def test_step_parse_commits_nothing_when_a_later_row_is_bad():
+    """an overflow (or a bad slot id) in row i used to leave rows 0..i-1 committed — num_tokens advanced for some
+    slots only.  The validation pass runs over every row before the first write."""
+    max_seqs, W, vocab, width = 4, 12, 100, 4
+    rows = np.arange(max_seqs * W, dtype=np.int32).reshape(max_seqs, W) % vocab
+    num_tokens = np.array([3, 5, 10, 2], np.int32)          # slot 2 has room for 2 more tokens only
+    out = np.array([[7, 8, -1, -1], [9, -1, -1, -1], [1, 2, 3, -1], [4, -1, -1, -1]], np.int32)
+    emit, flat, total = np.zeros(max_seqs, np.int32), np.zeros(max_seqs * width, np.int32), np.zeros(1, np.int64)
+
+    def call(live):
+        live = np.asarray(live, np.int64)
+        return N.lib().aic_step_parse(len(live), live.ctypes.data, max_seqs, out.ctypes.data, width, vocab, rows.ctypes.data, W,
+                                      num_tokens.ctypes.data, emit.ctypes.data, flat.ctypes.data, total.ctypes.data)
+
+    r0, n0 = rows.copy(), num_tokens.copy()
+    assert call([0, 1, 2, 3]) == N.AIC_ERR_INVALID and b"overflow" in N.lib().aic_last_error()
+    assert np.array_equal(rows, r0) and np.array_equal(num_tokens, n0)
+    for bad in (4, -1):
+        assert call([0, 1, bad, 3]) == N.AIC_ERR_INVALID and b"not a slot" in N.lib().aic_last_error()
+        assert np.array_equal(rows, r0) and np.array_equal(num_tokens, n0)
+    num_tokens[2] = 9                                        # now it fits exactly
+    assert call([0, 1, 2, 3]) == 0 and int(total[0]) == 7
+    assert num_tokens.tolist() == [5, 6, 12, 3] and rows[2, 9:12].tolist() == [1, 2, 3]

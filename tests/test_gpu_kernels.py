@@ -607,6 +607,101 @@ def test_verify_attention_ignores_empty_trailing_requests():
     assert torch.allclose(got, want, atol=1e-3, rtol=2 ** -8), float((got - want).abs().max())
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(Hq=32, Hkv=8, D=128, fp8=False, window=0, sinks=False),    # Llama-3.1-8B heads
+    dict(Hq=4, Hkv=1, D=128, fp8=False, window=0, sinks=False),     # their SP = 8 slice (waves = token ranges)
+    dict(Hq=32, Hkv=8, D=128, fp8=True, window=0, sinks=False),     # fp8 e4m3 cache
+    dict(Hq=64, Hkv=8, D=64, fp8=False, window=128, sinks=True),    # gpt-oss layer
+])
+def test_verify_attention_device_geometry_form_replayed_from_a_hip_graph(cfg):
+    """The call form a full-graph capture records (vllm_plugin/ulysses.py::_arctic_verify under a capturing stream): no
+    host-side request partition, request count / token count / max_query_len / max_seq_len frozen at capture-time upper
+    bounds, per-request lengths, query offsets, block table and q read from PERSISTENT device buffers.  The launch is
+    captured ONCE into a HIP graph and replayed over three different steps written into those buffers (fewer live requests
+    than captured, mixed query lengths incl. suffix-length drafts, contexts from 1 token to the bound); every replay's live
+    rows must equal the fp32 oracle at the kernel tolerance — atol 1e-3 + one bf16 ulp, the same bar as the eager forms,
+    so graph replay has its own guard besides tests/test_vllm_capture_gpu.py's hidden-state comparison (3e-2)."""
+    Hq, Hkv, D, bs = cfg["Hq"], cfg["Hkv"], cfg["D"], 16
+    B_cap, T_cap, MAXQ, MAXS = 16, 96, 33, 2048
+    blocks_per = MAXS // bs
+    nb = B_cap * blocks_per + 3
+    g = torch.Generator().manual_seed(23)
+    kc = torch.randn(nb, bs, Hkv, D, generator=g).to(torch.bfloat16)
+    vc = torch.randn(nb, bs, Hkv, D, generator=g).to(torch.bfloat16)
+    ks = vs = 1.0
+    kw = {}
+    if cfg["fp8"]:
+        ks, vs = 0.037, 0.019
+        kc, vc = O.fp8_sat(kc.float() / ks, "e4m3"), O.fp8_sat(vc.float() / vs, "e4m3")
+        kw = dict(k_scale=torch.tensor([ks], device=DEV), v_scale=torch.tensor([vs], device=DEV))
+    sinks = (torch.randn(Hq, generator=g) * 2).float() if cfg["sinks"] else None
+    if sinks is not None:
+        kw["sinks"] = sinks.to(DEV)
+    scale = D ** -0.5
+    # persistent buffers (what vLLM refreshes before a replay)
+    d_q = torch.zeros(T_cap, Hq, D, dtype=torch.bfloat16, device=DEV)
+    d_out = torch.zeros(T_cap, Hq, D, dtype=torch.bfloat16, device=DEV)
+    d_seq = torch.zeros(B_cap, dtype=torch.int32, device=DEV)
+    d_qsl = torch.zeros(B_cap + 1, dtype=torch.int32, device=DEV)
+    d_bt = torch.zeros(B_cap, blocks_per, dtype=torch.int32, device=DEV)
+    kcd, vcd = kc.to(DEV), vc.to(DEV)
+
+    def call():
+        _ops().verify_attention(d_q, kcd, vcd, d_bt, d_seq, d_qsl, MAXQ, MAXS, scale, out=d_out, sliding_window=cfg["window"], **kw)
+
+    steps = [
+        dict(q_lens=[1] * 9, ctxs=[1500, 33, 1, 700, 16, 17, 2048, 64, 999]),
+        dict(q_lens=[4, 4, 1, 33, 2, 4, 9], ctxs=[1200, 40, 5, 1999, 2, 310, 777]),
+        dict(q_lens=[4] * 16, ctxs=[100 + 121 * i for i in range(16)]),
+    ]
+
+    def load(step):
+        q_lens, ctxs = step["q_lens"], step["ctxs"]
+        B, T = len(q_lens), sum(q_lens)
+        assert B <= B_cap and T <= T_cap and max(ctxs) <= MAXS and all(c >= n for c, n in zip(ctxs, q_lens))
+        gg = torch.Generator().manual_seed(1000 + T)
+        q = torch.randn(T, Hq, D, generator=gg).to(torch.bfloat16)
+        perm = torch.randperm(nb, generator=gg)
+        bt = torch.zeros(B_cap, blocks_per, dtype=torch.int32)
+        p = 0
+        for i, c in enumerate(ctxs):
+            k = (c + bs - 1) // bs
+            bt[i, :k] = perm[p:p + k].to(torch.int32)
+            p += k
+        qsl = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+        d_q.zero_()
+        d_q[:T].copy_(q)
+        d_seq.copy_(torch.tensor(ctxs + [0] * (B_cap - B), dtype=torch.int32))
+        d_qsl.copy_(torch.tensor(list(qsl) + [int(qsl[-1])] * (B_cap - B), dtype=torch.int32))
+        d_bt.copy_(bt)
+        d_out.fill_(float("nan"))
+        return q, bt[:B], qsl, T
+
+    # warm-up outside the capture (workspace allocation, module load), then ONE capture
+    load(steps[0])
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        call()
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        call()
+    for step in steps:
+        q, bt, qsl, T = load(step)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        want = O.verify_attention(q, kc, vc, bt, step["ctxs"], qsl, scale, ks, vs, sliding_window=cfg["window"], sinks=sinks)
+        got = d_out[:T].float().cpu()
+        assert not torch.isnan(got).any()
+        assert torch.allclose(got, want, atol=1e-3, rtol=2 ** -8), (step["q_lens"], float((got - want).abs().max()))
+        # and the replay is the eager device-geometry call, bit for bit
+        d_out.fill_(float("nan"))
+        call()
+        torch.cuda.synchronize()
+        assert torch.equal(d_out[:T].float().cpu(), got)
+
+
 def test_verify_attention_unsupported_shapes():
     from arcticinference_amd._native import NativeError
     q, kc, vc, bt, qsl = _attn_case(1, 4, 1, 96, [2], [40], 16, seed=1)
@@ -702,6 +797,90 @@ def test_verify_attention_full_size_properties(kv):
         want = O.verify_attention(q[rows].cpu(), kc.cpu(), vc.cpu(), bt[i:i + 1], [ctxs[i]],
                                   np.array([0, q_lens[i]], dtype=np.int32), scale, ks, vs)
         assert torch.allclose(a[rows].cpu(), want, atol=1e-3, rtol=2 ** -8), (i, (a[rows].cpu() - want).abs().max())
+
+
+@pytest.mark.parametrize("window", [128, 0])
+def test_verify_attention_gpt_oss_full_batch_properties(window):
+    """BASELINE configs[4] at batch size: gpt-oss-120b heads (Hq 64, Hkv 8, D 64), B = 64 requests, ~4K-token contexts,
+    k = 3 drafts and suffix-length drafts, a sliding-window layer (128) and a full-attention layer (0), per-head sinks in
+    both.  The fp32 oracle is too slow for the whole batch: size-independent properties, then an oracle sample.
+    (1) paging: shuffled KV pages + permuted block table -> bit-identical;
+    (2) the host-partitioned call form and the generic one agree within the kernel tolerance;
+    (3) sinks: where the sink dominates the normaliser (sink logit +20: the keys' mass, ~e^9, is 2e-5 of it), raising every
+        head's sink by ln 2 halves the output — the sink is counted exactly once however the row's range was split;
+    (4) window: pages wholly below every request's window are poisoned with NaN -> unchanged (window layer only);
+    (5) linearity in V;
+    (6) four requests (first, last, longest draft, longest context) against the oracle."""
+    torch.manual_seed(11)
+    B, Hq, Hkv, D, bs = 64, 64, 8, 64, 16
+    rng = np.random.RandomState(9)
+    q_lens = [4] * 54 + [int(x) for x in rng.randint(5, 34, size=10)]
+    rng.shuffle(q_lens)
+    ctxs = [int(x) for x in rng.randint(3800, 4353, size=B)]
+    max_blocks = max((c + bs - 1) // bs for c in ctxs)
+    nb = B * max_blocks
+    bt = torch.randperm(nb).view(B, max_blocks).to(torch.int32)
+    kc = torch.randn(nb, bs, Hkv, D, device=DEV, dtype=torch.bfloat16)
+    vc = torch.randn(nb, bs, Hkv, D, device=DEV, dtype=torch.bfloat16)
+    v2 = torch.randn(nb, bs, Hkv, D, device=DEV, dtype=torch.bfloat16)
+    T = sum(q_lens)
+    q = torch.randn(T, Hq, D, device=DEV, dtype=torch.bfloat16)
+    qsl = torch.tensor(np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32), device=DEV)
+    seq = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
+    sinks = (torch.randn(Hq) * 2).float()
+    scale = D ** -0.5
+    ops = _ops()
+
+    def run(k, v, table, snk=sinks, **kw):
+        return ops.verify_attention(q, k, v, table.to(DEV), seq, qsl, max(q_lens), max(ctxs), scale, sliding_window=window,
+                                    sinks=None if snk is None else snk.to(DEV), **kw).float()
+
+    a = run(kc, vc, bt, q_lens_host=q_lens)
+    assert not torch.isnan(a).any()
+    # (1)
+    shuf = torch.randperm(nb)
+    inv = torch.empty_like(shuf)
+    inv[shuf] = torch.arange(nb)
+    a_shuf = run(kc[shuf.to(DEV)], vc[shuf.to(DEV)], inv[bt.long()].to(torch.int32), q_lens_host=q_lens)
+    assert torch.equal(a, a_shuf)
+    # (2)
+    b = run(kc, vc, bt)
+    assert torch.allclose(a, b, atol=1e-3, rtol=2 ** -8), (a - b).abs().max()
+    # (3) a dominating sink: doubling its weight halves the rows
+    big = torch.full((Hq,), 20.0)
+    s1 = run(kc, vc, bt, snk=big, q_lens_host=q_lens)
+    s2 = run(kc, vc, bt, snk=big + float(np.log(2.0)), q_lens_host=q_lens)
+    assert float(s1.abs().max()) > 1e-7                      # (not a comparison of zeros)
+    assert torch.allclose(s2, 0.5 * s1, atol=1e-10, rtol=2 ** -6), (s2 - 0.5 * s1).abs().max()
+    # and the sinks matter at all
+    nos = run(kc, vc, bt, snk=None, q_lens_host=q_lens)
+    assert not torch.allclose(a, nos, atol=1e-2)
+    # (4) nothing below the window is read
+    if window:
+        kp, vp = kc.clone(), vc.clone()
+        for i, c in enumerate(ctxs):
+            lo = (c - q_lens[i]) - window + 1            # first key the first query row may see
+            dead = max(lo, 0) // bs                      # pages wholly below it
+            kp[bt[i, :dead].long().to(DEV)] = float("nan")
+            vp[bt[i, :dead].long().to(DEV)] = float("nan")
+        for kw in (dict(q_lens_host=q_lens), {}):
+            p = run(kp, vp, bt, **kw)
+            assert torch.equal(p, run(kc, vc, bt, **kw))
+        del kp, vp
+    # (5) linearity in V (sink mass is part of the normaliser and the same in all three)
+    a2 = run(kc, v2, bt, q_lens_host=q_lens)
+    vsum = (vc.float() + v2.float()).to(torch.bfloat16)
+    a12 = run(kc, vsum, bt, q_lens_host=q_lens)
+    assert torch.allclose(a12, a + a2, atol=6e-3, rtol=2 ** -6), (a12 - a - a2).abs().max()
+    # (6) the oracle on four requests
+    qs = qsl.cpu().numpy()
+    kcc, vcc = kc.cpu(), vc.cpu()
+    for i in sorted({0, B - 1, int(np.argmax(q_lens)), int(np.argmax(ctxs))}):
+        rows = slice(int(qs[i]), int(qs[i + 1]))
+        want = O.verify_attention(q[rows].cpu(), kcc, vcc, bt[i:i + 1], [ctxs[i]], np.array([0, q_lens[i]], dtype=np.int32),
+                                  scale, 1.0, 1.0, sliding_window=window, sinks=sinks)
+        for got in (a, b):
+            assert torch.allclose(got[rows].cpu(), want, atol=1e-3, rtol=2 ** -8), (i, (got[rows].cpu() - want).abs().max())
 
 
 def test_verify_attention_lighter_trailing_splits():
@@ -995,6 +1174,31 @@ def test_lstm_speculator_full_size():
     rerun = lambda forced: O.lstm_generate_proposals(O.merge_lstm_checkpoint(ck), ids, hidden, 3, 3, True, fp8_head=False,
                                                      return_logits=True, forced_tokens=forced)[1]
     _check_tokens(got, want, logits, "full size", rerun=rerun)
+
+
+@pytest.mark.parametrize("B", [8, 32])
+def test_lstm_speculator_full_size_fp8_head(B):
+    """BASELINE configs[1]'s own arithmetic at its own size: the per-tensor fp8 e4m3 LM head (W8A8, dynamic activation
+    scale: arctic_speculator.py:706-751, fp8.py:207-223, :276-308) at V = 128256, Ds = 4096 — the 1.576 GB per call that
+    bench.py's `roofline_draft_model` times — for B = 8 and B = 32 rows (32 = the widest batch that still takes the fp8
+    head, arctic_speculator.py:726-728), every head of every row against the CPU oracle, teacher-forced after a
+    near-tie.  Parity unpinned against a running reference (vLLM not importable); the oracle restates its op sequence."""
+    from arcticinference_amd.speculator import ArcticLSTMSpeculator, LSTMSpeculatorConfig, random_lstm_weights
+    cfg = LSTMSpeculatorConfig(vocab_size=128256, input_hidden_dim=4096)
+    ck = random_lstm_weights(cfg, seed=6, std=0.02)
+    m = ArcticLSTMSpeculator(cfg, max_num_seqs=32, device=DEV, quantize_lm_head=True)
+    m.load_weights(ck.items())
+    g = torch.Generator().manual_seed(100 + B)
+    hidden = torch.randn(B, 4096, generator=g).to(torch.bfloat16)
+    ids = torch.randint(0, 128256, (B,), generator=g)
+    w = O.merge_lstm_checkpoint(ck)
+    want, logits = O.lstm_generate_proposals(w, ids, hidden, 3, 3, True, fp8_head=True, return_logits=True)
+    got = m.generate_proposals(ids.to(DEV), hidden.to(DEV), 3).cpu()
+    assert got.shape == (B, 3) and (got >= 0).all() and (got < 128256).all()
+    rerun = lambda forced: O.lstm_generate_proposals(w, ids, hidden, 3, 3, True, fp8_head=True, return_logits=True,
+                                                     forced_tokens=forced)[1]
+    _check_tokens(got, want, logits, f"full size fp8 head B={B}", ulps=4, rerun=rerun)
+    assert m.quantize_lm_head
 
 
 @pytest.mark.parametrize("B,tie,scale_input,fp8", [(3, False, False, False), (20, True, True, False), (64, False, True, False),

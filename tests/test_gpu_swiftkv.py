@@ -115,3 +115,44 @@ def test_swiftkv_select_graph_buffers_and_capture_mode():
     with pytest.raises(RuntimeError):
         from arcticinference_amd.swiftkv import row_gather
         row_gather([hid], [torch.empty_like(hid)], d(li))              # CPU tensors: no fallback
+
+
+def test_bulk_kv_write_torch_op_compiles_fullgraph_on_the_gpu():
+    """torch.ops.arctic_inference.reshape_and_cache_flash_bulk (reference schema, torch_bindings.cpp:5-18) on the MI355X:
+    a caller compiled with fullgraph=True (Dynamo + AOT functionalisation of the mutated cache lists) writes the same
+    bytes as the eager call and as the oracle, bf16 and fp8 caches; SwiftKVSelector.write_kv goes through the same op."""
+    from arcticinference_amd import py_custom_ops
+    from arcticinference_amd.swiftkv import SwiftKVSelector
+    assert py_custom_ops.try_load_torch_library()
+    L, H, D, nb, bs, T = 6, 8, 128, 40, 16, 200
+    g = torch.Generator().manual_seed(3)
+    wide = torch.randn(T, 2 * L * H * D + 8, generator=g).to(torch.bfloat16)
+    n = L * H * D
+    slots = torch.randperm(nb * bs, generator=g)[:T]
+    slots[5] = -1                                           # a padded token: skipped
+    for kv, cdt in (("auto", torch.bfloat16), ("fp8_e4m3", torch.float8_e4m3fn)):
+        ksc = [torch.tensor(0.5 + 0.03 * l) for l in range(L)]
+        vsc = [torch.tensor(0.25 + 0.02 * l) for l in range(L)]
+        want = [torch.zeros(2, nb, bs, H, D, dtype=cdt) for _ in range(L)]
+        O.kv_bulk_write(wide[:, :n], wide[:, n:2 * n], [c[0] for c in want], [c[1] for c in want], slots, kv, ksc, vsc, H, D)
+        wd = wide.to(DEV)
+        kd, vd, sd = wd[:, :n], wd[:, n:2 * n], slots.to(DEV)
+        ks_d, vs_d = [t.to(DEV) for t in ksc], [t.to(DEV) for t in vsc]
+
+        def step(k, v, kcs, vcs, sl):
+            py_custom_ops.reshape_and_cache_flash_bulk(k, v, kcs, vcs, sl, kv, ks_d, vs_d, H, D)
+            return k.float().sum()
+
+        torch._dynamo.reset()
+        mk = lambda: [torch.zeros(2, nb, bs, H, D, dtype=cdt, device=DEV) for _ in range(L)]
+        for fn in (step, torch.compile(step, fullgraph=True, backend="aot_eager")):
+            caches = mk()
+            fn(kd, vd, [c[0] for c in caches], [c[1] for c in caches], sd)
+            for a, b in zip(caches, want):
+                assert torch.equal(a.cpu().view(torch.uint8), b.view(torch.uint8)), kv
+        caches = mk()
+        sel = SwiftKVSelector(64, L, H, D, torch.bfloat16, DEV)
+        sel.write_kv(kd, vd, caches, sd, kv, ks_d, vs_d)
+        for a, b in zip(caches, want):
+            assert torch.equal(a.cpu().view(torch.uint8), b.view(torch.uint8)), kv
+    torch._dynamo.reset()

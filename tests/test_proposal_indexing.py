@@ -195,11 +195,12 @@ def test_mode_selection(monkeypatch):
     from arcticinference_amd.engine import SpecConfig
     from arcticinference_amd.vllm_plugin import runner_logic as RL
     monkeypatch.delenv(RL.INDEXING_ENV, raising=False)
-    assert RL.proposal_indexing(None) == RL.DEFAULT_INDEXING == "reference"
-    assert RL.proposal_indexing(SpecConfig()) == "reference"
-    assert RL.proposal_indexing(SpecConfig(proposal_indexing="single_advance")) == "single_advance"
-    monkeypatch.setenv(RL.INDEXING_ENV, "single_advance")
-    assert RL.proposal_indexing(SpecConfig(proposal_indexing="reference")) == "single_advance"   # the environment wins
+    # r04: the shipped default is the single count (what bench.py headlines); "reference" is the opt-in parity switch
+    assert RL.proposal_indexing(None) == RL.DEFAULT_INDEXING == "single_advance"
+    assert RL.proposal_indexing(SpecConfig()) == "single_advance"
+    assert RL.proposal_indexing(SpecConfig(proposal_indexing="reference")) == "reference"
+    monkeypatch.setenv(RL.INDEXING_ENV, "reference")
+    assert RL.proposal_indexing(SpecConfig(proposal_indexing="single_advance")) == "reference"   # the environment wins
     monkeypatch.setenv(RL.INDEXING_ENV, "twice")
     with pytest.raises(ValueError, match="proposal_indexing"):
         RL.proposal_indexing(None)

@@ -35,14 +35,18 @@ def _worker(rank, world, port, Hq, Hkv, D, N, out_q):
         n = N // world
         sl = slice(rank * n, (rank + 1) * n)
 
-        def attn(q_, k_, v_):
-            # plain causal attention over all N tokens with this rank's heads (fp32); inputs are strided views
+        def attn(q_, k_, v_, sinks=None):
+            # plain causal attention over all N tokens with this rank's heads (fp32); inputs are strided views.
+            # `sinks` [hq]: one extra soft-max term per head (gpt-oss), no value attached
             assert q_.shape == (N, hq * D) and k_.shape == (N, hkv * D)
             Q = q_.reshape(N, hq, D).transpose(0, 1)
             K = k_.reshape(N, hkv, D).transpose(0, 1).repeat_interleave(hq // hkv, 0)
             V = v_.reshape(N, hkv, D).transpose(0, 1).repeat_interleave(hq // hkv, 0)
             s = Q @ K.transpose(1, 2) / D ** 0.5
             s = s.masked_fill(~torch.tril(torch.ones(N, N, dtype=torch.bool)), float("-inf"))
+            if sinks is not None:
+                s = torch.cat([s, sinks.view(hq, 1, 1).expand(hq, N, 1)], dim=-1)
+                return (torch.softmax(s, -1)[..., :N] @ V).transpose(0, 1).reshape(N, hq * D).contiguous()
             return (torch.softmax(s, -1) @ V).transpose(0, 1).reshape(N, hq * D).contiguous()
 
         ua = UlyssesAttention(world, dist.group.WORLD, hq, hkv, D,
@@ -63,17 +67,36 @@ def _worker(rank, world, port, Hq, Hkv, D, N, out_q):
         v_loc = v.view(N, Hkv, D)[:, kv0:kv0 + hkv].reshape(N, hkv * D)
         shift = attn(q_loc, k_loc, v_loc)
         ok = ok and torch.allclose(shift, ref_all.view(N, Hq, D)[:, h0:h1].reshape(N, hq * D), atol=1e-5)
+        # per-head attention sinks under Ulysses.  Every head gets a DISTINCT sink; the rank attends with the
+        # slice the patched Attention layer takes (vllm_plugin/ulysses.py::_arctic_sinks -> sp_local_head_range); a wrong
+        # head-to-rank mapping mis-normalises the heads of every rank > 0.  Dense reference: all heads, all sinks.
+        from arcticinference_amd.ulysses import sp_local_head_range
+        sinks_all = torch.linspace(-2.0, 3.0, Hq)
+        s0, s1 = sp_local_head_range(Hq, world, rank)
+        assert (s0, s1) == (h0, h1)            # the same heads in SP mode and in shift mode (TP = 1 here)
+        out_s = ua.forward(q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(),
+                           lambda a, b, c: attn(a, b, c, sinks_all[s0:s1]))
+        ref_s = _full(q, k, v, Hq, Hkv, D, N, sinks_all)
+        ok = ok and torch.allclose(out_s, ref_s[sl], atol=1e-5) and not torch.allclose(ref_s, ref_all, atol=1e-3)
+        if world > 1:                           # and the mapping matters: the neighbouring rank's slice is wrong
+            w0, w1 = sp_local_head_range(Hq, world, (rank + 1) % world)
+            bad = ua.forward(q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(),
+                             lambda a, b, c: attn(a, b, c, sinks_all[w0:w1]))
+            ok = ok and not torch.allclose(bad, ref_s[sl], atol=1e-4)
         out_q.put((rank, bool(ok), tuple(out.shape)))
     finally:
         dist.destroy_process_group()
 
 
-def _full(q, k, v, Hq, Hkv, D, N):
+def _full(q, k, v, Hq, Hkv, D, N, sinks=None):
     Q = q.reshape(N, Hq, D).transpose(0, 1)
     K = k.reshape(N, Hkv, D).transpose(0, 1).repeat_interleave(Hq // Hkv, 0)
     V = v.reshape(N, Hkv, D).transpose(0, 1).repeat_interleave(Hq // Hkv, 0)
     s = Q @ K.transpose(1, 2) / D ** 0.5
     s = s.masked_fill(~torch.tril(torch.ones(N, N, dtype=torch.bool)), float("-inf"))
+    if sinks is not None:
+        s = torch.cat([s, sinks.view(Hq, 1, 1).expand(Hq, N, 1)], dim=-1)
+        return (torch.softmax(s, -1)[..., :N] @ V).transpose(0, 1).reshape(N, Hq * D)
     return (torch.softmax(s, -1) @ V).transpose(0, 1).reshape(N, Hq * D)
 
 
