@@ -860,7 +860,7 @@ def test_verify_attention_gpt_oss_full_batch_properties(window):
         kp, vp = kc.clone(), vc.clone()
         for i, c in enumerate(ctxs):
             lo = (c - q_lens[i]) - window + 1            # first key the first query row may see
-            dead = max(lo, 0) // bs                      # pages wholly below it
+            dead = (max(lo, 0) // 32 * 32) // bs         # pages wholly below its 32-token tile (the kernel starts at a tile boundary)
             kp[bt[i, :dead].long().to(DEV)] = float("nan")
             vp[bt[i, :dead].long().to(DEV)] = float("nan")
         for kw in (dict(q_lens_host=q_lens), {}):
