@@ -827,7 +827,7 @@ def test_verify_attention_gpt_oss_full_batch_properties(window):
     q = torch.randn(T, Hq, D, device=DEV, dtype=torch.bfloat16)
     qsl = torch.tensor(np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32), device=DEV)
     seq = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
-    sinks = (torch.randn(Hq) * 2).float()
+    sinks = (torch.randn(Hq) * 2 + 7.0).float()       # e^7 ~ 1100: comparable with the mass of ~4K keys (~6000) and of a 128-key window (~200)
     scale = D ** -0.5
     ops = _ops()
 
@@ -854,7 +854,7 @@ def test_verify_attention_gpt_oss_full_batch_properties(window):
     assert torch.allclose(s2, 0.5 * s1, atol=1e-10, rtol=2 ** -6), (s2 - 0.5 * s1).abs().max()
     # and the sinks matter at all
     nos = run(kc, vc, bt, snk=None, q_lens_host=q_lens)
-    assert not torch.allclose(a, nos, atol=1e-2)
+    assert not torch.allclose(a, nos, atol=2e-3)
     # (4) nothing below the window is read
     if window:
         kp, vp = kc.clone(), vc.clone()
@@ -1073,7 +1073,7 @@ def test_verify_attention_long_draft_split_counts(Hkv):
 # ------------------------------------------------------------------------------------------------
 # A7-A10 LSTM speculator
 # ------------------------------------------------------------------------------------------------
-def _check_tokens(got, want_toks, want_logits, tag, ulps=1, rerun=None):
+def _check_tokens(got, want_toks, want_logits, tag, ulps=1, rerun=None, count_by_near_ties=False):
     """EVERY head of EVERY row: the kernel's token must be the oracle's, or sit within `ulps` bf16 steps of the oracle's
     top logit (accumulation order differs between MFMA tiles and the CPU GEMM; on the fp8 head one bf16 ulp in an
     activation can flip its e4m3 code, a 6 % step on that element).  After a row parts from the oracle at such a
@@ -1084,16 +1084,21 @@ def _check_tokens(got, want_toks, want_logits, tag, ulps=1, rerun=None):
     B, k = want_toks.shape
     if not torch.equal(got, want_toks) and rerun is not None:
         want_logits = rerun(got)
-    bad = 0
+    bad = near = 0
     for b in range(B):
         for h in range(k):
             lg = want_logits[h][b].float()
+            top2 = torch.topk(lg, 2).values
+            near += float(top2[0] - top2[1]) <= max(abs(float(top2[0])), 1e-3) * 2 ** -7 * ulps
             if int(got[b, h]) == int(torch.argmax(lg)):
                 continue
             top, mine = float(lg.max()), float(lg[int(got[b, h])])
             assert top - mine <= max(abs(top), 1e-3) * 2 ** -7 * ulps, f"{tag}: row {b} head {h}: {mine} vs max {top}"
             bad += 1
-    assert bad <= max(1, B * k // 10), f"{tag}: {bad} near-tie mismatches"
+    # how many may part: a tenth of the heads — or, at the full vocabulary (128256 candidates: the oracle's own top-2 gap is
+    # inside the tolerance for a large share of the rows, counted above as `near`), three quarters of the pairs that CAN
+    assert bad <= (max(1, B * k // 10, near * 3 // 4) if count_by_near_ties else max(1, B * k // 10)), \
+        f"{tag}: {bad} near-tie mismatches ({near} of {B * k} oracle pairs are near-ties)"
 
 
 @pytest.mark.parametrize("B,fp8", [(1, False), (5, True), (16, True), (33, False), (64, False), (24, True)])
@@ -1193,11 +1198,28 @@ def test_lstm_speculator_full_size_fp8_head(B):
     ids = torch.randint(0, 128256, (B,), generator=g)
     w = O.merge_lstm_checkpoint(ck)
     want, logits = O.lstm_generate_proposals(w, ids, hidden, 3, 3, True, fp8_head=True, return_logits=True)
-    got = m.generate_proposals(ids.to(DEV), hidden.to(DEV), 3).cpu()
+    # the whole-draft entry point, with the bf16-rounded maximum logit of every head beside its token
+    from arcticinference_amd import _native as N
+    got_d = torch.full((B, 3), -1, dtype=torch.int64, device=DEV)
+    vals_d = torch.full((B, 3), float("nan"), dtype=torch.float32, device=DEV)
+    hid_d, ids_d = hidden.to(DEV), ids.to(torch.int32).to(DEV)
+    N.check(N.lib().aic_lstm_propose(m._h, hid_d.data_ptr(), None, ids_d.data_ptr(), B, 3, got_d.data_ptr(), vals_d.data_ptr(),
+                                     N.current_stream_ptr()))
+    torch.cuda.synchronize()
+    got, vals = got_d.cpu(), vals_d.cpu()
+    assert torch.equal(got, m.generate_proposals(ids.to(DEV), hid_d, 3).cpu())
     assert got.shape == (B, 3) and (got >= 0).all() and (got < 128256).all()
     rerun = lambda forced: O.lstm_generate_proposals(w, ids, hidden, 3, 3, True, fp8_head=True, return_logits=True,
                                                      forced_tokens=forced)[1]
-    _check_tokens(got, want, logits, f"full size fp8 head B={B}", ulps=4, rerun=rerun)
+    _check_tokens(got, want, logits, f"full size fp8 head B={B}", ulps=4, rerun=rerun, count_by_near_ties=True)
+    # the VALUE of the fused head: the kernel's maximum logit against the oracle's logit of the SAME token, teacher-forced
+    # with the kernel's tokens (so every head is judged on its own prefix) — the arithmetic of the W8A8 GEMM + arg-max
+    # itself, whatever a near-tie did to the token.  4 bf16 steps, as for the tokens (a flipped e4m3 activation code).
+    forced_logits = logits if torch.equal(got, want) else rerun(got)
+    for b in range(B):
+        for h in range(3):
+            ref = float(forced_logits[h][b][int(got[b, h])])
+            assert abs(float(vals[b, h]) - ref) <= max(abs(ref), 1e-3) * 2 ** -7 * 4, (b, h, float(vals[b, h]), ref)
     assert m.quantize_lm_head
 
 
