@@ -126,6 +126,8 @@ _SIGNATURES = {
     "aic_lstm_padding_size": (c_int, [c_int]),
     "aic_lstm_propose": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "aic_debug_lstm_fused": (c_int, [c_int]),
+    "aic_debug_lstm_cell_launches": (c_int, [c_int]),
+    "aic_debug_lstm_cell_trace": (c_int, [c_void_p]),
     "aic_lstm_begin": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "aic_lstm_head": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "aic_verify_attention_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -160,10 +160,14 @@ __global__ void __launch_bounds__(256)
 ln0_kernel(const uint16_t* __restrict__ hidden, const int32_t* __restrict__ hidden_index, int batch, int H, int MT,
            int scale_input, uint4* __restrict__ x_out, uint16_t* __restrict__ cell, int Ds,
            unsigned int* __restrict__ amax_bits, int n_amax, const int32_t* __restrict__ last_tokens,
-           int32_t* __restrict__ tokens) {
+           int32_t* __restrict__ tokens, unsigned int* __restrict__ sync_words, int n_sync) {
   __shared__ float sh[16];
   const int m = blockIdx.x;
   if (m == 0 && threadIdx.x < n_amax) amax_bits[threadIdx.x] = 0u;
+  // the slots of the draft's one-launch cells (lstm_cell_kernel mode 2) start every draft empty: the launch boundary behind
+  // this kernel orders these stores before the first slot store of a cell
+  if (m == 0 && sync_words)
+    for (int i = threadIdx.x; i < n_sync; i += 256) sync_words[i] = 0xffffffffu;     // kSyncEmpty
   // the whole-draft entry point hands the conditioning tokens over here (a launch of their own cost 4.8 us, rocprofv3)
   if (m == 0 && last_tokens && threadIdx.x < batch) tokens[threadIdx.x] = last_tokens[threadIdx.x];
   // zero initial cell state (arctic_speculator.py:781-785)
@@ -204,7 +208,9 @@ ln0_kernel(const uint16_t* __restrict__ hidden, const int32_t* __restrict__ hidd
 
 // ---- skinny GEMM: out[m][n] = sum_k X[m][k] * W[n][k],  M = 16*MT <= 64 ---------------------------
 // EPI 0: fp32 partials  part[split][m][n]          (gate projection, split-K over blockIdx.y)
-// EPI 1: arg-max of bf16(acc * scale) over the block's 64 rows -> best_val/best_idx[block][m]
+// EPI 1: arg-max of bf16(acc * scale) over the block's 64 rows -> best_val/best_idx[m][block]  (row-major per batch row
+//        since r04: the reduction over a row's blocks then reads 2 x 8 KB contiguous; as [block][m] every thread of it
+//        touched a cache line of its own — 4008 lines per workgroup, +4 us in the cell kernel's in-kernel trace)
 //
 // Pipeline: K is walked in chunks of S = 4 k-steps (4 KiB of weights per wave).  Weight fragments go
 // straight from HBM to VGPRs through a ring of FOUR register sets, three chunks (12 KiB per wave) ahead of
@@ -429,8 +435,9 @@ __device__ __forceinline__ void skinny_gemm_body(const GemmArgs& A, uint4 (*lds)
           bi = oi;
         }
       }
-      best_val[static_cast<int64_t>(bx) * (MT * 16) + tid] = bv;
-      best_idx[static_cast<int64_t>(bx) * (MT * 16) + tid] = bi == 0x7fffffff ? 0x7fffffff : bi + row_offset;
+      const int64_t n_blocks = (A.n_rowtiles + 3) / 4;
+      best_val[tid * n_blocks + bx] = bv;
+      best_idx[tid * n_blocks + bx] = bi == 0x7fffffff ? 0x7fffffff : bi + row_offset;
     }
   }
 }
@@ -475,11 +482,30 @@ skinny_head_xq_kernel(GemmArgs Hd) {
 // one workgroup per batch row; r() marks every place the reference materialises a bf16 tensor
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
-// The cell is two launches of kCellParts workgroups per batch row, split where the second normalisation needs a sum
-// over the whole row.  One 1024-thread workgroup per row (rounds 1-2) did all of it in one launch on 64 of the 256 CUs and
-// was bound by its own arithmetic there (two erf, three exp and ~25 bf16 roundings per element: 26-33 us per head,
-// rocprofv3); spread over 4 x 64 workgroups the same arithmetic is a few microseconds per launch.
+// The cell is kCellParts workgroups per batch row with two cross-workgroup steps: the second normalisation needs a sum over
+// the whole row, and the fp8 LM head's dynamic per-tensor scale needs the |max| over the whole batch.  History: one
+// 1024-thread workgroup per row (r01-r02) did everything on 64 of the 256 CUs and was bound by its own arithmetic there (two
+// erf, three exp, ~25 bf16 roundings per element: 26-33 us per head); r02-r03 cut the cell into two launches at the row sum
+// plus a third for the quantisation (11.6 + 11.6 + 4.7 us per head, rocprofv3).  r04 found what those microseconds are:
+// not arithmetic but DEPENDENT MEMORY ROUND TRIPS, ~2 us each on this part once a load leaves the XCD (the gate partials,
+// the arg-max partials and the embedding row were written by other CUs or never read): the first one-launch form (counters
+// in device memory between the phases, values in registers) still took 25.8 us, because it had kept the chain — arg-max
+// partials -> token -> embedding row + partials -> block sum -> second-pass loads -> share swap -> counter -> poll -> shares
+// -> third-pass loads -> atomicMax -> counter -> poll -> |max| — ten round trips.  This form issues every load that does
+// not depend on the token at the very top (all gate partials of the thread's columns, layer-norm weights, old cell state,
+// arg-max partials), the embedding row as soon as the token is known, and crosses workgroups through SLOTS instead of
+// counters: a part stores its share (agent-scope atomic store) into its own slot, which ln0_kernel set to a sentinel at the
+// start of the draft, and the readers poll the slots themselves — one store and one poll per step, nothing returned.
+// Modes 0 and 1 are the same code cut at the row sum into two launches (the head-by-head / vocab-parallel entry points,
+// and the A/B reference of mode 2: identical thread -> column mapping and reduction order, so the modes are bit-identical).
 constexpr int kCellParts = 4;
+constexpr int kCellThreads = 256;
+constexpr int kCellMaxIter = 2;          // own columns per thread: 4 x kCellMaxIter (Ds <= 8192)
+constexpr int kCellRowIter = 4 * kCellMaxIter;   // row-wide pass: 4 x kCellRowIter columns per thread
+constexpr int kSyncHeads = 16;
+constexpr int kSyncRowWords = 64 * kCellParts;   // per head: one row-sum share per (row, part) ...
+constexpr int kSyncStride = 2 * kSyncRowWords;   // ... and one |max| per workgroup (row, part)
+constexpr unsigned int kSyncEmpty = 0xffffffffu; // not a value a share or a |max| can take (both are non-negative floats)
 
 struct CellArgs {
   const float* part;   // [n_splits][m_pad][4 Ds] gate projection partials
@@ -493,22 +519,40 @@ struct CellArgs {
 
 __device__ __forceinline__ float cell_sigmoid(float x) { return r(1.0f / (1.0f + expf(-x))); }
 
-// torch.add(states, z, alpha=emb_weight / state_weight) for gate column n (z column j)
-__device__ __forceinline__ float cell_added(const CellArgs& a, int m, const uint16_t* z, int n, int j) {
-  float s = 0.0f;
-  for (int sp = 0; sp < a.n_splits; ++sp) s += a.part[(static_cast<int64_t>(sp) * a.m_pad + m) * (4 * a.Ds) + n];
-  return r(fmaf(a.alpha, bf16_to_f32(z[j]), r(s)));
+// sum over the split-K partials of gate columns n .. n + 3 of row m (r(s) of it is the bf16 projection output)
+__device__ __forceinline__ float4 cell_part4(const CellArgs& a, int m, int n) {
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int sp = 0; sp < a.n_splits; ++sp) {
+    const float4 p = *reinterpret_cast<const float4*>(a.part + (static_cast<int64_t>(sp) * a.m_pad + m) * (4 * a.Ds) + n);
+    s.x += p.x;
+    s.y += p.y;
+    s.z += p.z;
+    s.w += p.w;
+  }
+  return s;
+}
+__device__ __forceinline__ void unpack4(uint2 v, float (&f)[4]) {
+  f[0] = bf16_to_f32(static_cast<uint16_t>(v.x & 0xffff));
+  f[1] = bf16_to_f32(static_cast<uint16_t>(v.x >> 16));
+  f[2] = bf16_to_f32(static_cast<uint16_t>(v.y & 0xffff));
+  f[3] = bf16_to_f32(static_cast<uint16_t>(v.y >> 16));
+}
+// torch.add(states, z, alpha=emb_weight / state_weight) for four gate columns (s = their projection sums, zz = z's columns)
+__device__ __forceinline__ void cell_added4(float alpha, float4 s, uint2 zz, float (&out)[4]) {
+  float zf[4];
+  unpack4(zz, zf);
+  out[0] = r(fmaf(alpha, zf[0], r(s.x)));
+  out[1] = r(fmaf(alpha, zf[1], r(s.y)));
+  out[2] = r(fmaf(alpha, zf[2], r(s.z)));
+  out[3] = r(fmaf(alpha, zf[3], r(s.w)));
 }
 
-// phase A, workgroup (row m, part q): new cell state of columns [q Ds/4, (q+1) Ds/4) and their share of its mean square.
-// The first normalisation's row sum is computed by every part for itself (4 Ds partial reads from L2: nothing next to a
-// cross-workgroup step).
 // Fused draft path (PrevArgmax.best_val != nullptr): the arg-max over the previous head's per-workgroup partials is
 // finished HERE — every part of a row reduces the same n_blocks candidates to the same token (ties to the lowest index, so
 // the order of the reduction does not matter), part 0 publishes it (tokens[m], the draft's output column) — instead of in
 // a launch of its own between the LM head and this cell.
 struct PrevArgmax {
-  const float* best_val;      // [n_blocks][m_pad] or nullptr: the token is tokens[m] already
+  const float* best_val;      // [m_pad][n_blocks] or nullptr: the token is tokens[m] already
   const int32_t* best_idx;
   int n_blocks;
   int32_t* tokens;            // [m_pad] written by part 0
@@ -542,29 +586,124 @@ __device__ __forceinline__ void block_argmax(float& bv, int& bi, float* s_v, int
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(1024)
-lstm_cell_a_kernel(CellArgs a, const uint16_t* __restrict__ cln_w, const uint16_t* __restrict__ cln_b,
-                   uint16_t* __restrict__ cell, float* __restrict__ ss2_part, PrevArgmax pa) {
+// Cross-workgroup steps of mode 2: agent-scope atomic stores and loads only (coherent across the XCDs' L2s by themselves:
+// no release / acquire fence, i.e. no L2 write-back or invalidate).  Every slot a poll waits for belongs to a live workgroup
+// of the same launch that stores into it unconditionally; all 4 x m_pad workgroups of the launch are resident together
+// (256 threads, 49 VGPRs).  A poll still gives up after ~2^22 rounds rather than hang the device should that be violated.
+__device__ __forceinline__ void slot_store(unsigned int* slot, unsigned int bits) {
+  __hip_atomic_store(slot, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned int slot_poll(const unsigned int* slot) {
+  unsigned int v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int rounds = 0; v == kSyncEmpty && rounds < (1 << 22); ++rounds) {
+    __builtin_amdgcn_s_sleep(1);
+    v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return v;
+}
+
+struct CellSync {
+  unsigned int* row_share;    // [m_pad][kCellParts] kSyncEmpty at the start of the draft (ln0_kernel), then the share's bits
+  unsigned int* wg_amax;      // [m_pad][kCellParts] likewise: the workgroup's |max| bits
+  uint4* h_fp8;               // fragment-major e4m3 activations (fp8 LM head) or nullptr
+  float* x_scale;
+  int64_t* trace;             // debug (aic_debug_lstm_cell_trace): per workgroup 8 timestamps (100 MHz) at the phase boundaries
+};
+
+// mode 0: gates + new cell state, row-sum shares to ss2_part (stops there);  mode 1: state from `cell` + ss2_part (a launch
+// boundary lies between 0 and 1);  mode 2: both in one launch, + the fp8 head's activation quantisation when sy.h_fp8.
+// Workgroup (row m, part q) owns columns [q Ds/4, (q+1) Ds/4); thread t of it the four columns 4 t .. 4 t + 3 of every
+// 1024-column block of that range (and of the whole row, for the first normalisation's sum).
+__global__ void __launch_bounds__(kCellThreads)
+lstm_cell_kernel(CellArgs a, int mode, const uint16_t* __restrict__ cln_w, const uint16_t* __restrict__ cln_b,
+                 const uint16_t* __restrict__ sln_w, const uint16_t* __restrict__ sln_b, uint16_t* __restrict__ cell,
+                 float* __restrict__ ss2_part, PrevArgmax pa, int MT, uint4* __restrict__ h_out,
+                 unsigned int* __restrict__ amax_bits, CellSync sy) {
   __shared__ float sh[16];
   __shared__ float s_v[16];
   __shared__ int s_i[16];
+  __shared__ float s_share[kCellParts];
   const int m = blockIdx.x, q = blockIdx.y, Ds = a.Ds;
-  if (m >= a.batch) return;
-  int tok;
-  if (pa.best_val != nullptr) {
-    float bv = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int b = threadIdx.x; b < pa.n_blocks; b += blockDim.x) {
-      const float v = pa.best_val[static_cast<int64_t>(b) * a.m_pad + m];
-      const int i = pa.best_idx[static_cast<int64_t>(b) * a.m_pad + m];
-      if (v > bv || (v == bv && i < bi)) {
-        bv = v;
-        bi = i;
+  const int j0 = q * (Ds / kCellParts), j1 = j0 + Ds / kCellParts;
+  const int tid = threadIdx.x;
+  if (m >= a.batch) {
+    // rows of the padded batch: zero activations for the GEMMs that follow (no part in any cross-workgroup step)
+    if (mode != 0)
+      for (int j = j0 + 4 * tid; j < j1; j += 4 * kCellThreads) {
+        uint2* hp = reinterpret_cast<uint2*>(h_out + xunit_bf16(m, j >> 3, MT)) + ((j >> 2) & 1);
+        *hp = make_uint2(0u, 0u);
+        if (mode == 2 && sy.h_fp8) reinterpret_cast<uint32_t*>(sy.h_fp8 + xunit_fp8(m, j >> 4, MT))[(j >> 2) & 3] = 0u;
       }
+    return;
+  }
+  const bool do_a = mode != 1, do_b = mode != 0;
+  int64_t* tr = sy.trace ? sy.trace + (static_cast<int64_t>(m) * kCellParts + q) * 12 : nullptr;
+#define AIC_STAMP(i_) if (tr && tid == 0) tr[i_] = static_cast<int64_t>(__builtin_amdgcn_s_memrealtime());
+  AIC_STAMP(0)
+
+  // ---- 1. every load that does not depend on the token, issued together (one memory round trip) ----
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  const bool finish_argmax = do_a && pa.best_val != nullptr;
+  if (finish_argmax) {
+    // eight (value, index) pairs per thread in flight at once (a load-compare-load loop ran at one memory round trip per
+    // iteration: +2.7 us on the heads that finish an arg-max, in-kernel trace)
+    const float* pv = pa.best_val + static_cast<int64_t>(m) * pa.n_blocks;
+    const int32_t* pi = pa.best_idx + static_cast<int64_t>(m) * pa.n_blocks;
+    for (int b0 = 0; b0 < pa.n_blocks; b0 += 8 * kCellThreads) {
+      float v[8];
+      int ix[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + u * kCellThreads + tid;
+        const bool ok = b < pa.n_blocks;
+        v[u] = ok ? pv[b] : -INFINITY;
+        ix[u] = ok ? pi[b] : 0x7fffffff;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (v[u] > bv || (v[u] == bv && ix[u] < bi)) {
+          bv = v[u];
+          bi = ix[u];
+        }
     }
+  }
+  float4 row_c[kCellRowIter];                        // candidate-gate projection sums of the whole row (first normalisation)
+  float4 own_c[kCellMaxIter], own_i[kCellMaxIter], own_f[kCellMaxIter], own_o[kCellMaxIter];
+  uint2 w_cln[kCellMaxIter], b_cln[kCellMaxIter], w_sln[kCellMaxIter], b_sln[kCellMaxIter], c_old[kCellMaxIter];
+  if (do_a) {
+#pragma unroll
+    for (int i = 0; i < kCellRowIter; ++i) {
+      const int j = 4 * tid + i * 4 * kCellThreads;
+      if (j < Ds) row_c[i] = cell_part4(a, m, 3 * Ds + j);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < kCellMaxIter; ++it) {
+    const int j = j0 + 4 * tid + it * 4 * kCellThreads;
+    if (j >= j1) continue;
+    if (do_a) {
+      own_c[it] = cell_part4(a, m, 3 * Ds + j);
+      own_i[it] = cell_part4(a, m, Ds + j);
+      own_f[it] = cell_part4(a, m, j);
+      w_cln[it] = *reinterpret_cast<const uint2*>(cln_w + j);
+      b_cln[it] = *reinterpret_cast<const uint2*>(cln_b + j);
+    }
+    if (do_b) {
+      own_o[it] = cell_part4(a, m, 2 * Ds + j);
+      w_sln[it] = *reinterpret_cast<const uint2*>(sln_w + j);
+      b_sln[it] = *reinterpret_cast<const uint2*>(sln_b + j);
+    }
+    c_old[it] = *reinterpret_cast<const uint2*>(cell + static_cast<int64_t>(m) * Ds + j);
+  }
+
+  // ---- 2. the token, then its embedding row (second round trip) ----
+  AIC_STAMP(1)
+  int tok;
+  if (finish_argmax) {
     block_argmax(bv, bi, s_v, s_i);
     tok = bi;
-    if (q == 0 && threadIdx.x == 0) {
+    if (q == 0 && tid == 0) {
       pa.tokens[m] = bi;
       if (pa.out_tokens) pa.out_tokens[static_cast<int64_t>(m) * pa.out_stride + pa.out_col] = bi;
       if (pa.out_vals) pa.out_vals[static_cast<int64_t>(m) * pa.out_stride + pa.out_col] = bv;
@@ -574,68 +713,166 @@ lstm_cell_a_kernel(CellArgs a, const uint16_t* __restrict__ cln_w, const uint16_
   }
   if (tok < 0 || tok >= a.vocab_rows) tok = 0;  // never read outside the table
   const uint16_t* z = a.emb + static_cast<int64_t>(tok) * Ds;
-
-  float ss = 0.0f;
-  for (int j = threadIdx.x; j < Ds; j += blockDim.x) {
-    const float c = cell_added(a, m, z, 3 * Ds + j, j);
-    ss += r(c * c);
-  }
-  ss = block_sum(ss, sh);
-  const float rs = r(rsqrtf(r(r(ss / static_cast<float>(Ds)) + 1e-6f)));
-
-  const int j0 = q * (Ds / kCellParts), j1 = j0 + Ds / kCellParts;
-  float ss2 = 0.0f;
-  for (int j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
-    float y = r(cell_added(a, m, z, 3 * Ds + j, j) * rs);
-    y = r(bf16_to_f32(cln_w[j]) * y);
-    y = r(y + bf16_to_f32(cln_b[j]));
-    const float cand = r(r(gelu_erf(y)) * cell_sigmoid(cell_added(a, m, z, Ds + j, j)));                        // * input gate
-    const float kept = r(bf16_to_f32(cell[static_cast<int64_t>(m) * Ds + j]) * cell_sigmoid(cell_added(a, m, z, j, j)));  // * forget gate
-    const float cnew = r(kept + cand);
-    cell[static_cast<int64_t>(m) * Ds + j] = f32_to_bf16(cnew);
-    ss2 += r(cnew * cnew);
-  }
-  ss2 = block_sum(ss2, sh);
-  if (threadIdx.x == 0) ss2_part[m * kCellParts + q] = ss2;
-}
-
-// phase B, workgroup (row m, part q): state = gelu(state_ln(cell)) * output gate for its columns, written fragment-major
-// for the next GEMMs; the row's mean square is the sum of the kCellParts shares in part order
-__global__ void __launch_bounds__(256)
-lstm_cell_b_kernel(CellArgs a, const uint16_t* __restrict__ sln_w, const uint16_t* __restrict__ sln_b,
-                   const uint16_t* __restrict__ cell, const float* __restrict__ ss2_part, int MT, uint4* __restrict__ h_out,
-                   unsigned int* __restrict__ amax_bits) {
-  const int m = blockIdx.x, q = blockIdx.y, Ds = a.Ds;
-  const int k0 = q * (Ds / 8 / kCellParts), k1 = k0 + Ds / 8 / kCellParts;
-  if (m >= a.batch) {
-    for (int k8 = k0 + threadIdx.x; k8 < k1; k8 += blockDim.x) h_out[xunit_bf16(m, k8, MT)] = make_uint4(0, 0, 0, 0);
-    return;
-  }
-  int tok = a.tokens[m];
-  if (tok < 0 || tok >= a.vocab_rows) tok = 0;
-  const uint16_t* z = a.emb + static_cast<int64_t>(tok) * Ds;
-  float ss2 = 0.0f;
-  for (int p = 0; p < kCellParts; ++p) ss2 += ss2_part[m * kCellParts + p];
-  const float rs = r(rsqrtf(r(r(ss2 / static_cast<float>(Ds)) + 1e-6f)));
-  float amax = 0.0f;
-  for (int k8 = k0 + threadIdx.x; k8 < k1; k8 += blockDim.x) {
-    const uint4 c8 = *reinterpret_cast<const uint4*>(cell + static_cast<int64_t>(m) * Ds + k8 * 8);
-    const uint16_t* cv = reinterpret_cast<const uint16_t*>(&c8);
-    uint16_t h[8];
+  uint2 z_row[kCellRowIter], z_own[kCellMaxIter];
+  if (do_a) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int j = k8 * 8 + e;
-      float y = r(bf16_to_f32(cv[e]) * rs);
-      y = r(bf16_to_f32(sln_w[j]) * y);
-      y = r(y + bf16_to_f32(sln_b[j]));
-      const float st = r(r(gelu_erf(y)) * cell_sigmoid(cell_added(a, m, z, 2 * Ds + j, j)));  // * output gate
+    for (int i = 0; i < kCellRowIter; ++i) {
+      const int j = 4 * tid + i * 4 * kCellThreads;
+      if (j < Ds) z_row[i] = *reinterpret_cast<const uint2*>(z + j);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < kCellMaxIter; ++it) {
+    const int j = j0 + 4 * tid + it * 4 * kCellThreads;
+    if (j < j1) z_own[it] = *reinterpret_cast<const uint2*>(z + j);
+  }
+
+  float cn[kCellMaxIter][4];     // new cell state of this thread's columns (bf16 values)
+  AIC_STAMP(2)
+  if (do_a) {
+    // first normalisation: its row sum is computed by every part for itself
+    float ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kCellRowIter; ++i) {
+      const int j = 4 * tid + i * 4 * kCellThreads;
+      if (j >= Ds) continue;
+      float c[4];
+      cell_added4(a.alpha, row_c[i], z_row[i], c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ss += r(c[e] * c[e]);
+    }
+    ss = block_sum(ss, sh);
+    AIC_STAMP(3)
+    const float rs = r(rsqrtf(r(r(ss / static_cast<float>(Ds)) + 1e-6f)));
+    float ss2 = 0.0f;
+#pragma unroll
+    for (int it = 0; it < kCellMaxIter; ++it) {
+      const int j = j0 + 4 * tid + it * 4 * kCellThreads;
+      if (j >= j1) continue;
+      float c[4], gi[4], gf[4], wv[4], bw[4], ov[4];
+      cell_added4(a.alpha, own_c[it], z_own[it], c);
+      cell_added4(a.alpha, own_i[it], z_own[it], gi);
+      cell_added4(a.alpha, own_f[it], z_own[it], gf);
+      unpack4(w_cln[it], wv);
+      unpack4(b_cln[it], bw);
+      unpack4(c_old[it], ov);
+      uint16_t nb[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float y = r(c[e] * rs);
+        y = r(wv[e] * y);
+        y = r(y + bw[e]);
+        const float cand = r(r(gelu_erf(y)) * cell_sigmoid(gi[e]));           // * input gate
+        const float kept = r(ov[e] * cell_sigmoid(gf[e]));                    // * forget gate
+        const float cnew = r(kept + cand);
+        nb[e] = f32_to_bf16(cnew);
+        ss2 += r(cnew * cnew);
+        cn[it][e] = cnew;
+      }
+      c_old[it] = make_uint2(static_cast<uint32_t>(nb[0]) | (static_cast<uint32_t>(nb[1]) << 16),
+                             static_cast<uint32_t>(nb[2]) | (static_cast<uint32_t>(nb[3]) << 16));
+    }
+    ss2 = block_sum(ss2, sh);
+    // (global stores go out BEHIND the block reductions: a barrier waits for every store issued before it)
+#pragma unroll
+    for (int it = 0; it < kCellMaxIter; ++it) {
+      const int j = j0 + 4 * tid + it * 4 * kCellThreads;
+      if (j < j1) *reinterpret_cast<uint2*>(cell + static_cast<int64_t>(m) * Ds + j) = c_old[it];
+    }
+    if (mode == 0) {
+      if (tid == 0) ss2_part[m * kCellParts + q] = ss2;
+      return;
+    }
+    // the row's parts meet: own share into its slot, then poll the four slots (lanes 0-3 of the first wave, one each)
+    AIC_STAMP(4)
+    if (tid == 0) slot_store(sy.row_share + m * kCellParts + q, __float_as_uint(ss2));
+    if (tid < kCellParts) s_share[tid] = __uint_as_float(slot_poll(sy.row_share + m * kCellParts + tid));
+    __syncthreads();
+  } else {
+    if (tid < kCellParts) s_share[tid] = ss2_part[m * kCellParts + tid];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kCellMaxIter; ++it) unpack4(c_old[it], cn[it]);
+  }
+  // second normalisation: the row's mean square is the sum of the kCellParts shares in part order
+  AIC_STAMP(5)
+  float ss2 = 0.0f;
+  for (int p = 0; p < kCellParts; ++p) ss2 += s_share[p];
+  const float rs2 = r(rsqrtf(r(r(ss2 / static_cast<float>(Ds)) + 1e-6f)));
+  float amax = 0.0f;
+  uint32_t hb[kCellMaxIter][2];   // this thread's state values as packed bf16 pairs (for the quantisation)
+#pragma unroll
+  for (int it = 0; it < kCellMaxIter; ++it) {
+    const int j = j0 + 4 * tid + it * 4 * kCellThreads;
+    if (j >= j1) continue;
+    float go[4], wv[4], bw[4];
+    cell_added4(a.alpha, own_o[it], z_own[it], go);
+    unpack4(w_sln[it], wv);
+    unpack4(b_sln[it], bw);
+    uint16_t h[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float y = r(cn[it][e] * rs2);
+      y = r(wv[e] * y);
+      y = r(y + bw[e]);
+      const float st = r(r(gelu_erf(y)) * cell_sigmoid(go[e]));  // * output gate
       h[e] = f32_to_bf16(st);
       amax = fmaxf(amax, fabsf(st));
     }
-    h_out[xunit_bf16(m, k8, MT)] = *reinterpret_cast<uint4*>(h);
+    hb[it][0] = static_cast<uint32_t>(h[0]) | (static_cast<uint32_t>(h[1]) << 16);
+    hb[it][1] = static_cast<uint32_t>(h[2]) | (static_cast<uint32_t>(h[3]) << 16);
   }
+  AIC_STAMP(8)
   for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
-  if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(amax));
+  if ((tid & 63) == 0) s_v[tid >> 6] = amax;
+  AIC_STAMP(9)
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < kCellMaxIter; ++it) {
+    const int j = j0 + 4 * tid + it * 4 * kCellThreads;
+    if (j < j1) reinterpret_cast<uint2*>(h_out + xunit_bf16(m, j >> 3, MT))[(j >> 2) & 1] = make_uint2(hb[it][0], hb[it][1]);
+  }
+  AIC_STAMP(6)
+  const bool quantise = mode == 2 && sy.h_fp8 != nullptr;
+  if (tid == 0) {
+    float wg = s_v[0];
+    for (int w = 1; w < kCellThreads / 64; ++w) wg = fmaxf(wg, s_v[w]);
+    // the batch |max| for a reader behind the launch (quant_act_kernel, the XQ head): ONE atomic per workgroup — one per
+    // wave (512 on one address at 32 rows) serialised into ~6 us that the next barrier's vmcnt(0) then waited for (in-kernel
+    // trace, r04).  With the quantisation in this launch the slots carry it instead.
+    if (quantise)
+      slot_store(sy.wg_amax + m * kCellParts + q, __float_as_uint(wg));
+    else
+      atomicMax(amax_bits, __float_as_uint(wg));
+  }
+  if (!quantise) return;
+  // ---- dynamic per-tensor quantisation for the fp8 LM head (fp8.py:303-308; quant_act_kernel's arithmetic on the values
+  // this thread still holds): needs the |max| over the WHOLE batch -> every live workgroup has stored its own into its slot,
+  // and every workgroup polls all of them (thread t slot t: batch x kCellParts <= 256 slots) and takes the maximum
+  float all = 0.0f;
+  if (tid < a.batch * kCellParts) all = __uint_as_float(slot_poll(sy.wg_amax + tid));
+  for (int off = 32; off > 0; off >>= 1) all = fmaxf(all, __shfl_xor(all, off));
+  __syncthreads();                               // (s_v is reused)
+  if ((tid & 63) == 0) s_v[tid >> 6] = all;
+  __syncthreads();
+  all = s_v[0];
+  for (int w = 1; w < kCellThreads / 64; ++w) all = fmaxf(all, s_v[w]);
+  const float scale = fmaxf(all / 448.0f, 1.0f / (448.0f * 512.0f));
+  const float inv = 1.0f / scale;
+  if (m == 0 && q == 0 && tid == 0) *sy.x_scale = scale;
+  AIC_STAMP(7)
+#undef AIC_STAMP
+#pragma unroll
+  for (int it = 0; it < kCellMaxIter; ++it) {
+    const int j = j0 + 4 * tid + it * 4 * kCellThreads;
+    if (j >= j1) continue;
+    const uint32_t p0 = hb[it][0], p1 = hb[it][1];
+    const float f0 = clamp448(bf16_to_f32(static_cast<uint16_t>(p0 & 0xffff)) * inv);
+    const float f1 = clamp448(bf16_to_f32(static_cast<uint16_t>(p0 >> 16)) * inv);
+    const float f2 = clamp448(bf16_to_f32(static_cast<uint16_t>(p1 & 0xffff)) * inv);
+    const float f3 = clamp448(bf16_to_f32(static_cast<uint16_t>(p1 >> 16)) * inv);
+    reinterpret_cast<uint32_t*>(sy.h_fp8 + xunit_fp8(m, j >> 4, MT))[(j >> 2) & 3] = pack4_fp8(f0, f1, f2, f3);
+  }
 }
 
 // ---- MLP speculator head (ArcticMLPSpeculator.generate_states, arctic_speculator.py:264-283): everything between
@@ -797,13 +1034,24 @@ argmax_finish_kernel(const float* __restrict__ best_val, const int32_t* __restri
   const int m = blockIdx.x;
   float bv = -INFINITY;
   int bi = 0x7fffffff;
-  for (int b = threadIdx.x; b < n_blocks; b += 256) {
-    const float v = best_val[static_cast<int64_t>(b) * m_pad + m];
-    const int i = best_idx[static_cast<int64_t>(b) * m_pad + m];
-    if (v > bv || (v == bv && i < bi)) {
-      bv = v;
-      bi = i;
+  const float* pv = best_val + static_cast<int64_t>(m) * n_blocks;
+  const int32_t* pi = best_idx + static_cast<int64_t>(m) * n_blocks;
+  for (int b0 = 0; b0 < n_blocks; b0 += 8 * 256) {     // eight pairs per thread in flight (see lstm_cell_kernel)
+    float v[8];
+    int ix[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = b0 + u * 256 + static_cast<int>(threadIdx.x);
+      const bool ok = b < n_blocks;
+      v[u] = ok ? pv[b] : -INFINITY;
+      ix[u] = ok ? pi[b] : 0x7fffffff;
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (v[u] > bv || (v[u] == bv && ix[u] < bi)) {
+        bv = v[u];
+        bi = ix[u];
+      }
   }
   for (int off = 32; off > 0; off >>= 1) {
     const float ov = __shfl_xor(bv, off);
@@ -854,7 +1102,8 @@ struct aic_lstm {
   uint4 *x0 = nullptr, *h_bf16 = nullptr, *h_fp8 = nullptr;
   uint16_t* cell = nullptr;
   float* part = nullptr;
-  float* ss2_part = nullptr;   // [64][kCellParts] row sums between the two cell launches
+  float* ss2_part = nullptr;   // [64][kCellParts] row-sum shares of the cell's parts
+  unsigned int* sync = nullptr;   // [kSyncHeads][kSyncStride] slots of the one-launch cell (emptied by ln0_kernel)
   float* best_val = nullptr;
   int32_t* best_idx = nullptr;
   int32_t* tokens = nullptr;
@@ -1052,14 +1301,13 @@ static int run_head(aic_lstm* m, int head_index, hipStream_t s, int64_t* out_tok
                                m->gate_rowtiles, steps_total, steps_total / splits, m->part, 4 * Ds, nullptr, 1.0f, 0,
                                0, nullptr, nullptr);
     if (rc != AIC_OK) return rc;
-    // 2. cell update (two launches: see kCellParts)
+    // 2. cell update: the two-launch form of lstm_cell_kernel (mode 0, launch boundary, mode 1)
     CellArgs ca{m->part, splits, mpad, B, m->tokens, static_cast<const uint16_t*>(m->w.forget_emb), 0x7fffffff, m->alpha, Ds};
-    hipLaunchKernelGGL(lstm_cell_a_kernel, dim3(mpad, kCellParts), dim3(1024), 0, s, ca,
-                       static_cast<const uint16_t*>(m->w.cell_ln_w), static_cast<const uint16_t*>(m->w.cell_ln_b), m->cell,
-                       m->ss2_part, PrevArgmax{});
-    hipLaunchKernelGGL(lstm_cell_b_kernel, dim3(mpad, kCellParts), dim3(128), 0, s, ca,
-                       static_cast<const uint16_t*>(m->w.state_ln_w), static_cast<const uint16_t*>(m->w.state_ln_b),
-                       static_cast<const uint16_t*>(m->cell), m->ss2_part, mt, m->h_bf16, m->amax + head_index);
+    for (int mode = 0; mode < 2; ++mode)
+      hipLaunchKernelGGL(lstm_cell_kernel, dim3(mpad, kCellParts), dim3(kCellThreads), 0, s, ca, mode,
+                         static_cast<const uint16_t*>(m->w.cell_ln_w), static_cast<const uint16_t*>(m->w.cell_ln_b),
+                         static_cast<const uint16_t*>(m->w.state_ln_w), static_cast<const uint16_t*>(m->w.state_ln_b),
+                         m->cell, m->ss2_part, PrevArgmax{}, mt, m->h_bf16, m->amax + head_index, CellSync{});
     if ((rc = launch_status("lstm_cell_kernel")) != AIC_OK) return rc;
   }
   // 3. LM head + fused arg-max
@@ -1113,6 +1361,8 @@ int aic_quantize_fp8_per_tensor(const void* src_bf16, void* dst_fp8, float* scal
 int aic_lstm_create(const aic_lstm_config* cfg, const aic_lstm_weights* w, aic_lstm** out) {
   AIC_REQUIRE(cfg && w && out, "null argument to aic_lstm_create");
   AIC_REQUIRE(cfg->inner_dim > 0 && cfg->inner_dim % 512 == 0, "inner_dim must be a positive multiple of 512");
+  AIC_REQUIRE(cfg->inner_dim <= 4 * kCellMaxIter * 4 * kCellThreads, "inner_dim above %d is not supported by the cell kernel",
+              4 * kCellMaxIter * 4 * kCellThreads);
   AIC_REQUIRE(cfg->input_hidden_dim > 0 && cfg->input_hidden_dim % 256 == 0,
               "input_hidden_dim must be a positive multiple of 256");
   AIC_REQUIRE(cfg->vocab_size > 0 && cfg->n_predict > 0 && cfg->max_batch > 0 && cfg->max_batch <= 64,
@@ -1144,7 +1394,9 @@ int aic_lstm_create(const aic_lstm_config* cfg, const aic_lstm_weights* w, aic_l
   AIC_ALLOC(m->h_fp8, static_cast<size_t>(mpad) * Ds);
   AIC_ALLOC(m->cell, static_cast<size_t>(mpad) * Ds * 2);
   AIC_ALLOC(m->part, static_cast<size_t>(m->gate_splits) * mpad * 4 * Ds * 4);
-  AIC_ALLOC(m->ss2_part, static_cast<size_t>(mpad) * kCellParts * sizeof(float));
+  AIC_ALLOC(m->ss2_part, static_cast<size_t>(64) * kCellParts * sizeof(float));
+  AIC_ALLOC(m->sync, static_cast<size_t>(kSyncHeads) * kSyncStride * sizeof(unsigned int));
+  AIC_HIP_TRY(hipMemset(m->sync, 0xff, static_cast<size_t>(kSyncHeads) * kSyncStride * sizeof(unsigned int)));
   AIC_ALLOC(m->best_val, static_cast<size_t>(m->head_blocks) * mpad * 4);
   AIC_ALLOC(m->best_idx, static_cast<size_t>(m->head_blocks) * mpad * 4);
   AIC_ALLOC(m->tokens, static_cast<size_t>(mpad) * 4);
@@ -1332,7 +1584,7 @@ int aic_mlp_create_stacked(const aic_lstm_config* cfg, const aic_mlp_weights* w,
 void aic_lstm_destroy(aic_lstm* m) {
   if (!m) return;
   void* bufs[] = {m->proj0_t, m->proj1_t, m->head_t, m->head8_t, m->x0,   m->h_bf16, m->h_fp8,
-                  m->cell,    m->part,    m->ss2_part, m->best_val, m->best_idx, m->tokens, m->amax, m->x_scale};
+                  m->cell,    m->part,    m->ss2_part, m->best_val, m->best_idx, m->tokens, m->amax, m->x_scale, m->sync};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (void* b : m->mlp_owned)
@@ -1356,7 +1608,7 @@ static int lstm_begin(aic_lstm* m, const void* hidden, const int32_t* hidden_ind
   m->cur_mt = pad_mt(batch);
   hipLaunchKernelGGL(ln0_kernel, dim3(m->cur_mt * 16), dim3(256), 0, s, static_cast<const uint16_t*>(hidden),
                      hidden_index, batch, m->cfg.input_hidden_dim, m->cur_mt, m->cfg.scale_input, m->x0, m->cell,
-                     m->cfg.inner_dim, m->amax, 64, last_tokens, m->tokens);
+                     m->cfg.inner_dim, m->amax, 64, last_tokens, m->tokens, m->sync, m->sync ? kSyncHeads * kSyncStride : 0);
   return launch_status("ln0_kernel");
 }
 
@@ -1376,6 +1628,8 @@ int aic_lstm_head(aic_lstm* m, int head_index, const int32_t* last_tokens, int b
 }
 
 static std::atomic<int> g_lstm_xq{0};
+static int64_t* g_lstm_cell_trace = nullptr;   // aic_debug_lstm_cell_trace
+static std::atomic<int> g_lstm_cell_launches{1};   // aic_debug_lstm_cell_launches: 1 = one cell launch per head (default), 3 = three
 
 // The whole k-head draft of the LSTM speculator in 3 k + 3 launches (12 at k = 3; the head-by-head form takes 5-6 per
 // head + 1): the gate projection of head h + 1 shares a launch with the LM head of head h (skinny_pair_kernel), the arg-max
@@ -1421,16 +1675,29 @@ static int propose_fused(aic_lstm* m, int k, int64_t* out_tokens, float* out_val
     CellArgs ca{m->part, splits, mpad, B, m->tokens, static_cast<const uint16_t*>(m->w.forget_emb), 0x7fffffff, m->alpha, Ds};
     PrevArgmax pa{};
     if (h > 0) pa = PrevArgmax{m->best_val, m->best_idx, m->head_blocks, m->tokens, out_tokens, out_vals, k, h - 1};
-    hipLaunchKernelGGL(lstm_cell_a_kernel, dim3(mpad, kCellParts), dim3(1024), 0, s, ca,
-                       static_cast<const uint16_t*>(m->w.cell_ln_w), static_cast<const uint16_t*>(m->w.cell_ln_b), m->cell,
-                       m->ss2_part, pa);
-    hipLaunchKernelGGL(lstm_cell_b_kernel, dim3(mpad, kCellParts), dim3(128), 0, s, ca,
-                       static_cast<const uint16_t*>(m->w.state_ln_w), static_cast<const uint16_t*>(m->w.state_ln_b),
-                       static_cast<const uint16_t*>(m->cell), m->ss2_part, mt, m->h_bf16, m->amax + h);
-    if ((rc = launch_status("lstm_cell_kernel")) != AIC_OK) return rc;
-    if (fp8 && !xq) {
-      hipLaunchKernelGGL(quant_act_kernel, dim3(64), dim3(256), 0, s, m->h_bf16, m->h_fp8, m->amax + h, m->x_scale, Ds, mt);
-      if ((rc = launch_status("quant_act_kernel")) != AIC_OK) return rc;
+    // ONE cell launch per head (mode 2: row-sum and |max| steps inside the launch, the fp8 head's activations quantised from
+    // registers): 4 x mpad workgroups of 256 threads, all resident at once.  Drafts of more than kSyncHeads heads, and
+    // aic_debug_lstm_cell_launches(3), keep the three-launch form (mode 0, mode 1, quant_act_kernel).
+    const bool one_launch = g_lstm_cell_launches.load() == 1 && h < kSyncHeads && m->sync != nullptr;
+    const uint16_t *clw = static_cast<const uint16_t*>(m->w.cell_ln_w), *clb = static_cast<const uint16_t*>(m->w.cell_ln_b);
+    const uint16_t *slw = static_cast<const uint16_t*>(m->w.state_ln_w), *slb = static_cast<const uint16_t*>(m->w.state_ln_b);
+    if (one_launch) {
+      unsigned int* sw = m->sync + static_cast<size_t>(h) * kSyncStride;
+      CellSync sy{sw, sw + kSyncRowWords, (fp8 && !xq) ? m->h_fp8 : nullptr, m->x_scale,
+                  g_lstm_cell_trace ? g_lstm_cell_trace + static_cast<int64_t>(h) * 64 * kCellParts * 12 : nullptr};
+      hipLaunchKernelGGL(lstm_cell_kernel, dim3(mpad, kCellParts), dim3(kCellThreads), 0, s, ca, 2, clw, clb, slw, slb, m->cell,
+                         m->ss2_part, pa, mt, m->h_bf16, m->amax + h, sy);
+      if ((rc = launch_status("lstm_cell_kernel")) != AIC_OK) return rc;
+    } else {
+      hipLaunchKernelGGL(lstm_cell_kernel, dim3(mpad, kCellParts), dim3(kCellThreads), 0, s, ca, 0, clw, clb, slw, slb, m->cell,
+                         m->ss2_part, pa, mt, m->h_bf16, m->amax + h, CellSync{});
+      hipLaunchKernelGGL(lstm_cell_kernel, dim3(mpad, kCellParts), dim3(kCellThreads), 0, s, ca, 1, clw, clb, slw, slb, m->cell,
+                         m->ss2_part, PrevArgmax{}, mt, m->h_bf16, m->amax + h, CellSync{});
+      if ((rc = launch_status("lstm_cell_kernel")) != AIC_OK) return rc;
+      if (fp8 && !xq) {
+        hipLaunchKernelGGL(quant_act_kernel, dim3(64), dim3(256), 0, s, m->h_bf16, m->h_fp8, m->amax + h, m->x_scale, Ds, mt);
+        if ((rc = launch_status("quant_act_kernel")) != AIC_OK) return rc;
+      }
     }
     const GemmArgs Hd = head_args(h);
     if (h + 1 < k) {
@@ -1472,6 +1739,18 @@ static int propose_fused(aic_lstm* m, int k, int64_t* out_tokens, float* out_val
 }
 
 static std::atomic<int> g_lstm_fused{1};
+// debug / A-B aid: launches per cell in the fused draft schedule — 1 (default: lstm_cell_kernel mode 2) or 3 (mode 0,
+// mode 1, quant_act_kernel); bit-identical results
+// debug: the next fused drafts record, per head and workgroup (row, part), 8 timestamps (100 MHz ticks) at the phase
+// boundaries of lstm_cell_kernel into buf[head][64][4][12] (device memory, int64); nullptr switches it off
+int aic_debug_lstm_cell_trace(int64_t* buf) {
+  g_lstm_cell_trace = buf;
+  return AIC_OK;
+}
+int aic_debug_lstm_cell_launches(int n) {
+  g_lstm_cell_launches.store(n == 3 ? 3 : 1);
+  return AIC_OK;
+}
 int aic_debug_lstm_fused(int on) {     // 0 head by head, 1 fused (default), 2 fused + on-the-fly fp8 activation quantisation
   g_lstm_fused.store(on);
   g_lstm_xq.store(on == 2 ? 1 : 0);

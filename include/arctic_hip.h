@@ -336,6 +336,12 @@ int aic_lstm_propose(aic_lstm* m, const void* hidden, const int32_t* hidden_inde
  * head, 3 k + 3 with a bf16 one), 0 the head-by-head one (5-6 launches per head), 2 the fused one with the fp8 head
  * quantising its activations on the way into LDS (no quant launch; measured slower); all compute the same tokens. */
 int aic_debug_lstm_fused(int on);
+/* debug aid: launches per LSTM cell in the fused schedule: 1 (default) = one launch whose parts meet at counters in device
+ * memory (row sum of the second normalisation, batch |max| of the fp8 head's activation scale), 3 = gates / state /
+ * quantisation as three launches (r03's form); bit-identical results. */
+int aic_debug_lstm_cell_launches(int n);
+/* debug aid: per-phase timestamps of the one-launch cell, buf[head][64 rows][4 parts][12] int64 in device memory (NULL = off) */
+int aic_debug_lstm_cell_trace(int64_t* buf);
 /* single-head entry points for the vocab-parallel (TP/SP > 1) loop, where an all-gather of
  * (value, index) sits between heads.  State lives in the handle. */
 int aic_lstm_begin(aic_lstm* m, const void* hidden, const int32_t* hidden_index, int batch, void* stream);

@@ -1155,11 +1155,16 @@ def test_lstm_fused_schedule_equals_head_by_head(B, fp8, Ds, H, V):
         for index in (None, hidx):
             t0, v0 = run(0, index)
             for mode in (1, 2):        # 2: the fp8 head quantises its activations on the way into LDS (built, not the default)
-                t1, v1 = run(mode, index)
-                assert torch.equal(t0, t1) and torch.equal(v0, v1), (B, fp8, mode, index is not None)
+                # r04: the cell as ONE launch (parts of a row and of the batch meet at device-memory counters inside it;
+                # the default) against gates / state / quantisation as three launches: same code cut at the counters
+                for cell_launches in (3, 1):
+                    lib.aic_debug_lstm_cell_launches(cell_launches)
+                    t1, v1 = run(mode, index)
+                    assert torch.equal(t0, t1) and torch.equal(v0, v1), (B, fp8, mode, cell_launches, index is not None)
             assert (t0 >= 0).all() and (t0 < V).all() and not torch.isnan(v0).any()
     finally:
         lib.aic_debug_lstm_fused(1)
+        lib.aic_debug_lstm_cell_launches(1)
 
 
 def test_lstm_speculator_full_size():
@@ -1393,11 +1398,49 @@ def test_lstm_hidden_index_and_errors():
     a = m.generate_proposals(ids.to(DEV), pool.to(DEV), 3, hidden_index=idx.to(DEV)).cpu()
     b = m.generate_proposals(ids.to(DEV), pool[idx].to(DEV), 3).cpu()
     assert torch.equal(a, b)
-    # HIP-graph replay path gives the same tokens
+    # HIP-graph replay (opt-in) gives the same tokens, with and without the row index
+    assert not m.use_graph
     m.use_graph = True
     c = m.generate_proposals(ids.to(DEV), pool[idx].to(DEV), 3).cpu()
-    c2 = m.generate_proposals(ids.to(DEV), pool[idx].to(DEV), 3).cpu()
+    c2 = m.generate_proposals(ids.to(DEV), pool.to(DEV), 3, hidden_index=idx.to(DEV)).cpu()
     assert torch.equal(b, c) and torch.equal(c, c2)
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_lstm_graph_replay_equals_eager(fp8):
+    """The draft as one HIP graph launch (use_graph=True; arctic_speculator.py:806-842 always replays a graph — here it is
+    opt-in, measured slower than eager launches on this runtime, see speculator.py::_replay_graph): bit-identical tokens to the eager launches for changing batch sizes (exact-size keys: no stale padded rows in
+    the fp8 head's activation scale), with and without the hidden-state row index, for two different hidden tensors (the
+    index form's graphs read the caller's tensor in place: its address is part of the key), for k = 2 and 3, interleaved
+    so that every graph is replayed after others ran on the same static buffers."""
+    from arcticinference_amd.speculator import ArcticLSTMSpeculator, LSTMSpeculatorConfig, random_lstm_weights
+    cfg = LSTMSpeculatorConfig(vocab_size=5000, input_hidden_dim=768, inner_dim="512", emb_dim="512", proj_dim="512",
+                               n_predict=3, num_lookahead_tokens=3)
+    ck = random_lstm_weights(cfg, seed=9, std=0.05)
+    mg = ArcticLSTMSpeculator(cfg, max_num_seqs=64, device=DEV, quantize_lm_head=fp8, use_graph=True)
+    me = ArcticLSTMSpeculator(cfg, max_num_seqs=64, device=DEV, quantize_lm_head=fp8)
+    for m in (mg, me):
+        m.load_weights(ck.items())
+    assert mg.use_graph and not me.use_graph
+    g = torch.Generator().manual_seed(3)
+    pools = [torch.randn(200, 768, generator=g).to(torch.bfloat16).to(DEV) for _ in range(2)]
+    cases = []
+    for rnd in range(3):
+        for B in (1, 7, 32, 33, 20, 64, 7):
+            for k in (3, 2):
+                cases.append((B, k, rnd % 2, (B + rnd) % 3 != 0))
+    for B, k, which, with_index in cases:
+        ids = torch.randint(0, 5000, (B,), generator=g).to(DEV)
+        idx = torch.randperm(200, generator=g)[:B].to(DEV)
+        if with_index:
+            a = mg.generate_proposals(ids, pools[which], k, hidden_index=idx)
+            b = me.generate_proposals(ids, pools[which], k, hidden_index=idx)
+        else:
+            rows = pools[which][idx.long()]
+            a = mg.generate_proposals(ids, rows, k)
+            b = me.generate_proposals(ids, rows, k)
+        assert a.shape == (B, k) and torch.equal(a.cpu(), b.cpu()), (B, k, which, with_index)
+    assert 0 < len(mg._graphs) <= mg._MAX_GRAPHS and len(me._graphs) == 0
 
 
 def test_quantize_fp8_per_tensor():

@@ -181,19 +181,28 @@ def attn_trace(n_short=59, n_long=5, q_short=1, q_long=33, ctx=4224, Hq=32, Hkv=
 def lstm(B, fp8=True):
     from arcticinference_amd.speculator import ArcticLSTMSpeculator, LSTMSpeculatorConfig, random_lstm_weights
     cfg = LSTMSpeculatorConfig(vocab_size=128256, input_hidden_dim=4096)
-    m = ArcticLSTMSpeculator(cfg, max_num_seqs=64, device=dev, quantize_lm_head=fp8)
+    m = ArcticLSTMSpeculator(cfg, max_num_seqs=64, device=dev, quantize_lm_head=fp8, use_graph=False)
     m.load_weights(random_lstm_weights(cfg, seed=0).items())
     hid = torch.randn(B, 4096, device=dev, dtype=torch.bfloat16)
     ids = torch.randint(0, 128256, (B,), device=dev)
     head_gb = 128256 * 4096 * (1 if (fp8 and B <= 32) else 2) / 1e9
     gate_gb = 4 * 4096 * 4096 * 2 / 1e9
-    for fused in (0, 1, 2):       # head-by-head schedule, the fused one, fused + on-the-fly fp8 activations (aic_debug_lstm_fused)
+    # head-by-head schedule, the fused one with the cell as three launches (r03) and as one (r04, the default), fused +
+    # on-the-fly fp8 activations (aic_debug_lstm_fused / aic_debug_lstm_cell_launches)
+    for name, fused, cell in (("head-by-head", 0, 1), ("fused, 3-launch cell", 1, 3), ("fused, 1-launch cell", 1, 1), ("fused+xq", 2, 1)):
         N.lib().aic_debug_lstm_fused(fused)
+        N.lib().aic_debug_lstm_cell_launches(cell)
         us = timeit(lambda: m.generate_proposals(ids, hid, 3), iters=10)
-        print(f"lstm B={B} fp8={fp8 and B <= 32} {('head-by-head', 'fused', 'fused+xq')[fused]}: {us:8.1f} us per 3-head propose; "
+        print(f"lstm B={B} fp8={fp8 and B <= 32} {name}: {us:8.1f} us per 3-head propose; "
               f"weights {3 * (head_gb + gate_gb):.2f} GB -> {3 * (head_gb + gate_gb) / us * 1e6 / 1e3:5.2f} TB/s "
               f"({3 * (head_gb + gate_gb) / us * 1e6 / 1e3 / 8:.2f} of 8 TB/s)")
     N.lib().aic_debug_lstm_fused(1)
+    N.lib().aic_debug_lstm_cell_launches(1)
+    for graph in (False, True):
+        m.use_graph = graph
+        us = timeit(lambda: m.generate_proposals(ids, hid, 3), iters=10)
+        print(f"lstm B={B} fp8={fp8 and B <= 32} fused, 1-launch cell, {'HIP graph replay' if graph else 'eager launches'}: {us:8.1f} us "
+              f"({3 * (head_gb + gate_gb) / us * 1e6 / 1e3 / 8:.2f} of 8 TB/s)")
     del m
     torch.cuda.empty_cache()
 
@@ -253,6 +262,11 @@ if __name__ == "__main__":
                 print(f"fp8 layout hpw={hpw} splits={sp}: ", end="")
                 attn_mix(B, 0, kv8=True)
         N.lib().aic_debug_attn_layout(0, 0)
+    if "ctxsweep" in what:    # short body over the context length: slope = streaming rate, intercept = fixed cost per call
+        for kv8 in (False, True):
+            for n in (32, 64):
+                for ctx in (544, 1056, 2112, 4224, 8448):
+                    attn_mix(n, 0, 1, 33, ctx=ctx, kv8=kv8)
     if "longctx" in what:     # the long-draft body alone over the context length: fixed cost and slope per 32-token tile
         for B in (16, 1):
             for ctx in (128, 512, 1024, 2048, 4096):
