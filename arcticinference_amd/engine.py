@@ -440,6 +440,11 @@ class HotPathEngine:
         pinB, devB = L.stage["B"]
         ob = L.offs_b
         view = lambda buf, off, n, dt, isz: buf[off:off + n * isz].view(dt)
+        if self.ulysses is not None and self.ulysses.pending_reshard is not None:
+            # an SP step's hidden states are on their way over xGMI on the resharding stream (ulysses.ReshardStream): the
+            # acceptance and the draft model read them — join here, behind everything enqueued since the layers' launches
+            self.ulysses.pending_reshard.wait()
+            self.ulysses.pending_reshard = None
         # ---- staging B (the GPU is busy with the attention launches from here on): only the synthetic target's tokens
         # are missing from it — row (request i, position p) gets the target's token for that position
         ql = (n_draft + 1).tolist()

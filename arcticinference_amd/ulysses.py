@@ -277,6 +277,10 @@ class UlyssesContext:
             kv_groups = (aa_group, aa, ag_group, ag)
         self.attn = UlyssesAttention(sp_size, group, lh.num_q_heads, lh.num_kv_heads, shape.head_size, all_to_all=all_to_all,
                                      kv_groups=kv_groups, all_gather=all_gather)
+        # the SP -> replicated resharding of a step's hidden states runs on a side stream (ReshardStream); the engine joins
+        # it (pending_reshard.wait()) before anything reads the gathered rows
+        self.reshard = ReshardStream(sp_size, sp_rank, group if all_to_all is None else None, device)
+        self.pending_reshard: Optional[ReshardHandle] = None
 
     def attention_layers(self, eng, T, bt, d_seq, d_qsl, max_q, max_ctx) -> None:
         from . import ops
@@ -315,9 +319,11 @@ class UlyssesContext:
 
         for layer in range(s.num_layers):
             self.attn.forward(q, k, v, lambda a, b, c, L=layer: attn(a, b, c, L))
-        # C6: the model's output rows of this rank's token slice, all-gathered over SP so that sampling and the draft
-        # model see every token (ulysses_forward, model_runner.py:202-209)
-        self.gather_hidden(eng.hidden[lo:lo + n], Tp)
+        # C6: the model's output rows of this rank's token slice, resharded over SP so that sampling and the draft model
+        # see every sampled token (ulysses_forward, model_runner.py:202-209) — on the side stream, joined by the engine
+        # before the acceptance; with the step's sampled rows known (every row of a verify step is one) the row form
+        # (a verify step samples from every row, so the stand-alone engine asks for all of them: the full form)
+        self.pending_reshard = self.reshard.gather(eng.hidden[lo:lo + n], Tp)
 
     def gather_hidden(self, local_rows: torch.Tensor, num_tokens: int) -> torch.Tensor:
         """[N/SP, hidden] -> [N, hidden] over the SP group (one all-gather per step)."""
@@ -328,6 +334,122 @@ class UlyssesContext:
             from .dist_utils import all_gather_into_tensor
             all_gather_into_tensor(out, local_rows.contiguous(), group=self.group)
         return out
+
+
+# --------------------------------------------------------------------------------------------------
+# SP -> replicated resharding of a step's hidden states, on a side stream
+# --------------------------------------------------------------------------------------------------
+class ReshardHandle:
+    """A resharding in flight: `wait()` orders the CURRENT stream behind it and hands back the tensor."""
+
+    def __init__(self, out: torch.Tensor, event, keep=()):
+        self._out, self._event, self._keep = out, event, keep
+
+    def wait(self) -> torch.Tensor:
+        if self._event is not None:
+            torch.cuda.current_stream(self._out.device).wait_event(self._event)
+            self._event = None
+        self._keep = ()
+        return self._out
+
+
+class ReshardStream:
+    """The layout change at the end of a Ulysses step — every rank holds the model's output rows of ITS token slice
+    ([N/SP, hidden]) and sampling / the draft model need rows of every slice — issued on a side HIP stream of its own
+    (BASELINE north_star: "shift-parallel TP<->SP resharding on a side stream").  The reference does it as one synchronous
+    all-gather of ALL N rows on the compute stream (ulysses_forward, model_runner.py:202-209), whatever the step samples.
+
+    gather(local_rows, num_tokens)            full form: all_gather_into_tensor -> [N, hidden], the reference's bytes.
+    gather(local_rows, num_tokens, rows=idx)  row form: only the global rows `idx` (the step's logits_indices; int64, on
+        the device) -> [len(idx), hidden].  Every rank picks the rows of `idx` that lie in its slice (zero rows for the
+        others) and ONE all-reduce over the SP group sums them; a row has exactly one owner, and the sum runs on the
+        rows' int32 bit patterns, so the result is the owner's bits, exactly (no float add, -0.0 stays -0.0).  Bytes per
+        rank: ~2 R H instead of the all-gather's (SP - 1) (N / SP) H — a 32K-token prefill chunk of 8192 tokens, 64
+        requests, hidden 8192 (BASELINE configs[3]): 2 MB instead of 117 MB over xGMI per step.
+
+    Both return a ReshardHandle at once: the collective (and, in the row form, the row pick) runs on the side stream
+    behind an event recorded on the caller's stream, and `handle.wait()` joins the caller's stream behind it — whatever the
+    caller enqueues in between (the next step's staging copies, the other lane's launches, the suffix-tree mirror
+    update) overlaps with the xGMI traffic.  On CPU tensors (gloo tests) and with group = None (single-process rehearsal:
+    local copies) the same calls run synchronously.
+    """
+
+    def __init__(self, sp_size: int, sp_rank: int, group, device=None):
+        self.sp_size, self.sp_rank, self.group = sp_size, sp_rank, group
+        self.device = torch.device(device) if device is not None else None
+        self._stream = None
+        self.calls = {"full": 0, "rows": 0}
+        self.bytes_moved = 0          # payload this rank contributed / received (diagnostics, not timing)
+
+    def _side(self, device):
+        if device.type != "cuda":
+            return None
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=device)
+        return self._stream
+
+    def gather(self, local_rows: torch.Tensor, num_tokens: int, rows: Optional[torch.Tensor] = None) -> ReshardHandle:
+        sp, n = self.sp_size, local_rows.shape[0]
+        assert n * sp == num_tokens, "the token count must be padded to a multiple of SP (pad_tokens_for_sp)"
+        dev = local_rows.device
+        side = self._side(dev)
+        event = None
+        if side is not None:
+            fork = torch.cuda.Event()
+            fork.record(torch.cuda.current_stream(dev))
+            side.wait_event(fork)
+        ctx = torch.cuda.stream(side) if side is not None else _NullContext()
+        with ctx:
+            # the row form pays when its all-reduce (~2 R rows per rank) moves less than the all-gather ((SP - 1) N / SP rows)
+            by_rows = rows is not None and 2 * rows.numel() < (sp - 1) * n
+            if not by_rows:
+                self.calls["full"] += 1
+                out = torch.empty((num_tokens, local_rows.shape[1]), dtype=local_rows.dtype, device=dev)
+                src = local_rows.contiguous()
+                if self.group is None:
+                    out.copy_(src.repeat(sp, 1))
+                else:
+                    from .dist_utils import all_gather_into_tensor
+                    all_gather_into_tensor(out, src, group=self.group)
+                self.bytes_moved += out.numel() * out.element_size()
+                keep = (src,)
+                if rows is not None:
+                    full, out = out, out.index_select(0, rows)
+                    keep = (src, full)
+            else:
+                self.calls["rows"] += 1
+                assert rows.dtype == torch.int64 and rows.device == dev
+                lo = self.sp_rank * n
+                mine = (rows >= lo) & (rows < lo + n)
+                picked = local_rows.index_select(0, (rows - lo).clamp_(0, n - 1))
+                out = torch.where(mine.unsqueeze(1), picked, torch.zeros((), dtype=picked.dtype, device=dev)).contiguous()
+                if self.group is not None:
+                    from .dist_utils import all_reduce
+                    bits = out.view(torch.int32) if (out.shape[1] * out.element_size()) % 4 == 0 else None
+                    assert bits is not None, "hidden size x element size must be a multiple of 4 bytes"
+                    all_reduce(bits, group=self.group)
+                elif sp > 1:
+                    # single-process rehearsal: the "other ranks" hold this rank's rows too
+                    out = local_rows.index_select(0, rows.remainder(n))
+                self.bytes_moved += 2 * out.numel() * out.element_size()
+                keep = (picked, mine)
+            if side is not None:
+                event = torch.cuda.Event()
+                event.record(side)
+                for t in (out,) + tuple(keep):
+                    t.record_stream(torch.cuda.current_stream(dev))
+        if side is not None:
+            # tensors made on the side stream's pool are handed to the caller's stream
+            out.record_stream(torch.cuda.current_stream(dev))
+        return ReshardHandle(out, event, keep)
+
+
+class _NullContext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
 
 
 # --------------------------------------------------------------------------------------------------

@@ -54,6 +54,25 @@ ua = UlyssesAttention(1, dist.group.WORLD, 8, 2, 128)
 q = torch.randn(4, 8 * 128, device=dev, generator=g).to(torch.bfloat16)
 k = torch.randn(4, 2 * 128, device=dev, generator=g).to(torch.bfloat16)
 assert torch.equal(ua.forward(q, k, k, lambda a, b, c: a * 2), q * 2)
+# the resharding stream (ulysses.ReshardStream): both forms over the real group on a side HIP stream, with main-stream work
+# enqueued between gather() and wait() — the int32 all-reduce of the row form goes through RCCL here
+from arcticinference_amd.ulysses import ReshardStream
+rs = ReshardStream(1, 0, dist.group.WORLD, dev)
+local = torch.randn(300, 4096, device=dev, generator=g).to(torch.bfloat16)
+local[7, 9] = -0.0
+busy = torch.randn(2048, 2048, device=dev, generator=g)
+h1 = rs.gather(local, 300)
+rows = torch.tensor([0, 7, 150, 299], device=dev)
+h2 = rs.gather(local, 300, rows=rows)
+for _ in range(4):
+    busy = busy @ busy.t() * 1e-3                   # runs on the main stream while the side stream reshards
+full, picked = h1.wait(), h2.wait()
+assert torch.equal(full.view(torch.int16), local.view(torch.int16))
+assert torch.equal(picked.view(torch.int16), local[rows].view(torch.int16))
+assert rs._stream is not None and rs._stream != torch.cuda.current_stream() and rs.calls == {"full": 2, "rows": 0}
+rs4 = ReshardStream(4, 0, None, dev)                # rehearsal form on the device: the row form is taken (2 R < 3 n)
+p4 = rs4.gather(local, 1200, rows=rows).wait()
+assert p4.shape == (4, 4096) and rs4.calls["rows"] == 1
 dist.barrier(device_ids=[0])
 torch.cuda.synchronize()
 dist.destroy_process_group()
