@@ -148,8 +148,14 @@ def _build():
             hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
             return self.mlp(hidden_states), residual
 
+    @support_torch_compile
     class LlamaSwiftKVPrefillRunner(nn.Module):
-        """First half (:219-281).  Holds the model in a list so that nn.Module does not register it a second time."""
+        """First half (:219-281), compiled like the reference's (both runners carry @support_torch_compile there).  Holds the
+        model in a list so that nn.Module does not register it a second time.  Everything in forward() is traceable by
+        Dynamo with fullgraph=True (tests/test_vllm_swiftkv_gpu.py compiles both runners): attention is one opaque custom op
+        (custom_ops.py), and the switch to the SP x TP group around the second half's projections is the reference's plain
+        pair of global stores (:258-262, :279-280) — set_shift_parallel_mode()'s generator-based context manager would be a
+        graph break."""
 
         def __init__(self, *, vllm_config, model, prefix: str = ""):
             super().__init__()
@@ -171,21 +177,29 @@ def _build():
                 hidden_states, residual, positions = sp_all_gather((hidden_states, residual, positions), sp.world_size,
                                                                     sp.device_group)
             later = m.layers[n_kv:]
-            with runner.set_shift_parallel_mode(True):      # the projections below belong to second-half layers (SP x TP shards)
-                swiftkv_hidden = m.norm_swiftkv(hidden_states + residual)
-                T = hidden_states.shape[0]
-                kv_size = later[0].self_attn.kv_size
-                # every later layer's K / V go into its column slice of one buffer each: the layout the bulk KV write reads
-                k_states = torch.empty(T, len(later) * kv_size, dtype=hidden_states.dtype, device=hidden_states.device)
-                v_states = torch.empty_like(k_states)
-                rotary = m.layers[0].self_attn.rotary_emb
-                q_scratch = torch.empty(T, kv_size, dtype=hidden_states.dtype, device=hidden_states.device)
-                for i, layer in enumerate(later):
-                    kv, _ = layer.self_attn.kv_proj_swiftkv(swiftkv_hidden)
-                    k, v = kv.split([kv_size, kv_size], dim=-1)
-                    _, k = rotary(positions, q_scratch, k)
-                    k_states[:, i * kv_size:(i + 1) * kv_size] = k
-                    v_states[:, i * kv_size:(i + 1) * kv_size] = v
+            # the projections below belong to second-half layers (SP x TP shards): TP group := SP_TP while they run
+            saved_mode, saved_tp = runner.SP_TP_MODE, parallel_state._TP
+            if getattr(parallel_state, "_SP_TP", None) is not None:
+                if not runner.is_shift_parallel_mode():
+                    parallel_state._ORIG_TP = parallel_state._TP
+                runner.SP_TP_MODE = True
+                parallel_state._TP = parallel_state._SP_TP
+            swiftkv_hidden = m.norm_swiftkv(hidden_states + residual)
+            T = hidden_states.shape[0]
+            kv_size = later[0].self_attn.kv_size
+            # every later layer's K / V go into its column slice of one buffer each: the layout the bulk KV write reads
+            k_states = torch.empty(T, len(later) * kv_size, dtype=hidden_states.dtype, device=hidden_states.device)
+            v_states = torch.empty_like(k_states)
+            rotary = m.layers[0].self_attn.rotary_emb
+            q_scratch = torch.empty(T, kv_size, dtype=hidden_states.dtype, device=hidden_states.device)
+            for i, layer in enumerate(later):
+                kv, _ = layer.self_attn.kv_proj_swiftkv(swiftkv_hidden)
+                k, v = kv.split([kv_size, kv_size], dim=-1)
+                _, k = rotary(positions, q_scratch, k)
+                k_states[:, i * kv_size:(i + 1) * kv_size] = k
+                v_states[:, i * kv_size:(i + 1) * kv_size] = v
+            runner.SP_TP_MODE = saved_mode
+            parallel_state._TP = saved_tp
             return hidden_states, residual, positions, k_states, v_states
 
     @support_torch_compile

@@ -111,6 +111,67 @@ def test_swiftkv_model_through_the_patched_runner(stub_vllm):
     assert sel is not None and sel.inputs is not None and model.model.decode_runner.inputs is sel.inputs
 
 
+def test_swiftkv_runners_trace_fullgraph(stub_vllm):
+    """Both runners of the SwiftKV model carry @support_torch_compile like the reference's (llama_swiftkv.py:218, :283); the
+    stand-in's decorator is a no-op, so what vLLM would do — trace each runner's forward with Dynamo, fullgraph — is done
+    here by hand: prefill runner AND decode runner compiled with fullgraph=True (any graph break raises), driven through the
+    patched execute_model for prefill + decode steps; logits equal the eager run's, the patched attention shows up as the
+    opaque custom op in every graph (the bulk KV write sits between the runners, in swiftkv_select, as in the reference)."""
+    H.load_plugin()
+    from vllm.config import (CacheConfig, CompilationConfig, DeviceConfig, ModelConfig, ParallelConfig, SchedulerConfig,
+                             VllmConfig, set_current_vllm_config)
+    from vllm.v1.worker.gpu_model_runner import GPUModelRunner
+
+    def run(compiled):
+        cfg = VllmConfig(model_config=ModelConfig(hf_config=_hf(), max_model_len=400, dtype=torch.bfloat16),
+                         parallel_config=ParallelConfig(), scheduler_config=SchedulerConfig(max_num_seqs=8),
+                         cache_config=CacheConfig(block_size=16),
+                         compilation_config=CompilationConfig(level=0, cudagraph_capture_sizes=()),
+                         device_config=DeviceConfig(DEV))
+        H.init_single_process_groups(cfg)
+        runner = GPUModelRunner(cfg, torch.device(DEV))
+        set_current_vllm_config(cfg)
+        runner.load_model()
+        model = runner.model
+        model.load_weights(_checkpoint().items())
+        runner.initialize_kv_cache((120, torch.bfloat16))
+        graphs = {"prefill": [], "decode": []}
+        if compiled:
+            core = model.model
+            for name, mod in (("prefill", core.prefill_runner), ("decode", core.decode_runner)):
+                def backend(gm, example_inputs, _name=name):
+                    graphs[_name].append(gm)
+                    return gm.forward
+                mod.forward = torch.compile(mod.forward, fullgraph=True, backend=backend, dynamic=True)
+        seen = []
+        orig_logits = model.compute_logits
+        model.compute_logits = lambda hidden, sm=None: seen.append(orig_logits(hidden, sm)) or seen[-1]
+        rng = np.random.default_rng(11)
+        sched = H.MiniScheduler(16, 400)
+        for i, n in enumerate((37, 64, 5)):
+            sched.add(f"r{i}", [int(t) for t in rng.integers(0, V, size=n)])
+        toks = []
+        for _ in range(4):
+            toks.append(sched.update(runner.execute_model(sched.schedule())))
+        return toks, [x.float().cpu() for x in seen], graphs
+
+    torch._dynamo.reset()
+    try:
+        want_toks, want_logits, _ = run(False)
+        got_toks, got_logits, graphs = run(True)
+    finally:
+        torch._dynamo.reset()
+    assert got_toks == want_toks
+    for a, b in zip(want_logits, got_logits):
+        assert a.shape == b.shape and torch.allclose(a, b, atol=2e-2 * float(a.abs().max()), rtol=0)
+    for name in ("prefill", "decode"):
+        assert graphs[name], f"the {name} runner was never traced"
+        for gm in graphs[name]:
+            targets = [str(n.target) for n in gm.graph.nodes if n.op == "call_function"]
+            n_attn = sum(t == "arctic_inference.attention" for t in targets)
+            assert n_attn == (N_KV if name == "prefill" else L - N_KV), (name, n_attn, targets)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # SP = 2 with shift parallelism (BASELINE config 3's arrangement): two processes on the one GPU, collectives over gloo
 # ---------------------------------------------------------------------------------------------------------------

@@ -12,11 +12,12 @@ def _purge():
     for name in [m for m in sys.modules if m == "vllm" or m.startswith("vllm.")]:
         del sys.modules[name]
     # patch classes are built against the vllm modules that were imported then
-    from arcticinference_amd.vllm_plugin import args, config, model_runner
+    from arcticinference_amd.vllm_plugin import args, config, model_runner, swiftkv_model
     model_runner._runner_patch = None
     model_runner.SP_TP_MODE = None
     args._built = None
     config._classes = None
+    swiftkv_model._CLASSES = None      # the SwiftKV model classes close over vllm modules too (second test of a process)
 
 
 def install():

@@ -1,7 +1,7 @@
 #!/bin/bash
 # bench.py at N = 1 and rehearsed SP 2 / 4 / 8 (one and two lanes): value, ms per round, roofline fraction
 set -e
-run() { echo "== $*"; timeout -k 10 300 python bench.py --no-cpu-baseline --no-replay-check "$@" 2>/dev/null | tail -1 | python -c "
+run() { echo "== $*"; timeout -k 10 300 python bench.py --no-cpu-baseline --no-replay-check --no-lstm-leg "$@" 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],3), round(d['roofline']['frac'],3), d['config']['lanes'])"; }
 run
