@@ -172,7 +172,10 @@ class HotPathEngine:
 
     def __init__(self, shape: ModelShape, spec: SpecConfig, max_num_seqs: int, max_model_len: int,
                  speculator: Optional[ArcticLSTMSpeculator], device: str = "cuda", ulysses=None, seed: int = 0,
-                 kv_cache_dtype: str = "auto"):
+                 kv_cache_dtype: str = "auto", suffix_owner=None):
+        """`suffix_owner` = (rank, world, exchange): rank-owned prompt trees (suffix_sharding.RankOwnedSuffix) — this rank
+        keeps the prompt trees of the slots it owns (slot % world == rank) and speculates for those requests only; `exchange`
+        all-reduces the [B, 34] int32 result matrix.  None: every prompt tree here (the reference's replicated control)."""
         self.shape, self.spec = shape, spec
         self.device = torch.device(device)
         self.max_num_seqs, self.max_model_len = max_num_seqs, max_model_len
@@ -192,6 +195,10 @@ class HotPathEngine:
         self.sp = 1 if ulysses is None else ulysses.sp_size
         self.suffix_cache = SuffixCache(spec.suffix_cache_max_depth) if (
             spec.enable_suffix_decoding or spec.method == "suffix") else None
+        self._sharded = None
+        if suffix_owner is not None and self.suffix_cache is not None:
+            from .suffix_sharding import RankOwnedSuffix
+            self._sharded = RankOwnedSuffix(self.suffix_cache, int(suffix_owner[0]), int(suffix_owner[1]), suffix_owner[2])
         s = shape
         self.hq_local = s.num_q_heads // self.sp
         self.hkv_local = max(1, s.num_kv_heads // self.sp)
@@ -272,7 +279,9 @@ class HotPathEngine:
         old = self.requests[slot]
         gen = np.asarray([first_token] if np.isscalar(first_token) else first_token, dtype=np.int32).reshape(-1)
         prompt_arr = np.asarray(prompt, dtype=np.int32)
-        if self.suffix_cache is not None:
+        if self._sharded is not None:
+            self._sharded.admit(slot, req_id, prompt_arr, gen, old_req_id=None if old is None else old.req_id)
+        elif self.suffix_cache is not None:
             if old is not None and self.suffix_cache.has_cached_prompt(old.req_id):
                 self.suffix_cache.evict_prompt(old.req_id)   # model_runner.py:675-678
             self.suffix_cache.cache_prompt_async(req_id, prompt_arr, gen)
@@ -284,6 +293,12 @@ class HotPathEngine:
                 old = self.requests[s]
                 if old is not None and self.suffix_cache.has_cached_prompt(old.req_id):
                     self.suffix_cache.evict_prompt(old.req_id)
+            if self._sharded is not None:
+                self._sharded.admit_many(list(slots), list(req_ids), prompts, first_tokens, n_threads=n_threads)
+                for s, rid, p, ft in zip(slots, req_ids, prompts, first_tokens):
+                    gen = np.asarray([ft] if np.isscalar(ft) else ft, dtype=np.int32).reshape(-1)
+                    self._admit(s, rid, np.asarray(p, dtype=np.int32), gen)
+                return
             self.suffix_cache.cache_prompts(list(req_ids), [list(p) for p in prompts], n_threads=n_threads)
         for s, rid, p, ft in zip(slots, req_ids, prompts, first_tokens):
             gen = np.asarray([ft] if np.isscalar(ft) else ft, dtype=np.int32).reshape(-1)
@@ -781,8 +796,13 @@ class HotPathEngine:
         if nq not in consts:
             consts[nq] = (np.full(nq, cfg.suffix_max_spec_factor, np.float32), np.full(nq, cfg.suffix_max_spec_offset, np.float32),
                           np.full(nq, cfg.suffix_min_token_prob, np.float32), np.ones(nq, np.int32))
-        o_tok, _, o_n, o_sc, _ = self.suffix_cache.speculate_batch_arrays(
-            req_ids if everyone else [req_ids[i] for i in where], flat, size.astype(np.int32), mst, *consts[nq])
+        asked_ids = req_ids if everyone else [req_ids[i] for i in where]
+        if self._sharded is not None:
+            # rank-owned prompt trees: this rank speculates for the slots it owns, one all-reduce brings the rest
+            o_tok, o_n, o_sc = self._sharded.propose(rows.tolist(), asked_ids, flat, size.astype(np.int32), mst, *consts[nq][:3])
+        else:
+            o_tok, _, o_n, o_sc, _ = self.suffix_cache.speculate_batch_arrays(asked_ids, flat, size.astype(np.int32), mst,
+                                                                              *consts[nq])
         if everyone:
             toks, n_tok, score = o_tok, o_n.astype(np.int32, copy=False), o_sc.astype(np.float32, copy=False)
         else:

@@ -95,6 +95,12 @@ def parse_args():
     ap.add_argument("--draft-model-per-request", action="store_true",
                     help="extension: requests that suffix decoding did not take still get the draft model's proposal in "
                          "steps where it took others (the reference gives the whole batch none, model_runner.py:616-618)")
+    ap.add_argument("--rank-owned-trees", action="store_true",
+                    help="N > 1: rank-owned prompt trees (arcticinference_amd/suffix_sharding.py) — a request's prompt tree lives "
+                         "on ONE rank (slot %% N), every rank speculates for its own requests only, one int32 all-reduce of "
+                         "the [B, 34] result matrix over a gloo control group brings the drafts together.  Bit-identical drafts "
+                         "to the replicated control (gloo tests, world sizes 2 and 8); its collective's latency on 8 GPUs is "
+                         "unmeasured, so it is opt-in")
     ap.add_argument("--no-shift-parallel", action="store_true",
                     help="N > 1: keep every step on the Ulysses all-to-all path (default: shift parallelism on, threshold "
                          "512 tokens, the reference's --enable-shift-parallel / --shift-parallel-threshold)")
@@ -383,8 +389,13 @@ def main():
         draft_cfg = cfg
         drafter = TimedDrafter(drafter)
 
+    suffix_owner = None
+    if args.rank_owned_trees and dist is not None and world > 1:
+        from arcticinference_amd.suffix_sharding import gloo_exchange
+        ctl = dist.group.WORLD if args.dist_backend == "gloo" else dist.new_group(backend="gloo")
+        suffix_owner = (rank, world, gloo_exchange(ctl))
     eng = HotPathEngine(shape, spec, B, max_model_len, drafter, device=dev, ulysses=ulysses, seed=args.seed,
-                        kv_cache_dtype=args.kv_dtype)
+                        kv_cache_dtype=args.kv_dtype, suffix_owner=suffix_owner)
 
     if args.no_suffix and drafter is not None:
         eng.plant_draft_prob = args.plant_draft_prob          # configs[1]: the synthetic target agrees with the draft at p per position
@@ -701,6 +712,8 @@ def main():
             "suffix_replay_check": replay_check,
             "reference_suffix_replay": golden_accept,
             "requests_replaced_in_timed_region": replaced_total,
+            "suffix_control_plane": ("rank-owned prompt trees (suffix_sharding.py), one int32 all-reduce per step"
+                                     if suffix_owner is not None else "replicated on every rank (the reference's arrangement)"),
             "draft_model_policy": ("per request (extension)" if spec.draft_model_per_request else
                                    "reference rule: no draft-model proposal in a step where suffix decoding takes a request"),
             **({"query_len_histogram": {str(i): int(c) for i, c in enumerate(eng.qlen_hist) if c}} if args.qlen_hist else {}),

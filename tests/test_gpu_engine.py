@@ -193,3 +193,87 @@ def test_two_interleaved_lanes_follow_the_reference_policy_per_lane_step(method,
     for c in pending:
         eng.finish(c)
     assert eng.suffix_cache._global_tree().selfcheck() == 0
+
+
+@pytest.mark.parametrize("method,with_lstm", [("suffix", False), ("arctic", True)])
+def test_rank_owned_prompt_trees_in_the_engine_equal_the_replicated_control(method, with_lstm):
+    """HotPathEngine(suffix_owner=(rank, 2, exchange)): two engines play the two ranks of an SP = 2 control plane on this one
+    GPU (a thread each; the exchange is the element-wise sum of the two ranks' result matrices, met at a barrier: what the
+    all-reduce gives), a third engine is the replicated form.  Same seeded workload, requests replaced along the way: per
+    step the three emit the same tokens and schedule the same drafts, and each sharded engine holds only its own slots'
+    prompt trees.  (World sizes 2 and 8 across processes: tests/test_suffix_sharding_gloo.py.)"""
+    import threading
+    from arcticinference_amd.workload import TokenSource
+    B, PL, GL, steps = 4, 96, 40, 30
+    src = TokenSource(vocab_size=2000, seed=5, n_motifs=3, motif_min=8, motif_max=16, p_motif=0.9)
+    streams = {r: np.asarray(src.stream(PL + GL + 80, r)) for r in range(40)}
+    barrier = threading.Barrier(2)
+    box = [None, None]
+
+    def exchange_for(rank):
+        def exchange(mat):
+            box[rank] = mat
+            barrier.wait(timeout=60)
+            total = box[0] + box[1]
+            barrier.wait(timeout=60)
+            return total
+        return exchange
+
+    def build(owner):
+        from arcticinference_amd.engine import HotPathEngine, ModelShape, SpecConfig
+        from arcticinference_amd.speculator import ArcticLSTMSpeculator, LSTMSpeculatorConfig, random_lstm_weights
+        shape = ModelShape(num_layers=2, num_q_heads=8, num_kv_heads=4, head_size=128, hidden_size=512, vocab_size=2000, block_size=16)
+        spec = SpecConfig(method=method, num_speculative_tokens=3, enable_suffix_decoding=True)
+        drafter = None
+        if with_lstm:
+            cfg = LSTMSpeculatorConfig(vocab_size=2000, input_hidden_dim=512, inner_dim="512", emb_dim="512", proj_dim="512")
+            drafter = ArcticLSTMSpeculator(cfg, max_num_seqs=4, device="cuda", quantize_lm_head=False)
+            drafter.load_weights(random_lstm_weights(cfg, seed=0, std=0.05).items())
+        return HotPathEngine(shape, spec, B, 400, drafter, device="cuda", seed=0, suffix_owner=owner)
+
+    def drive(eng, log, errors):
+        try:
+            next_id = [B]
+            eng.add_requests(list(range(B)), list(range(B)), [streams[r][:PL] for r in range(B)], [int(streams[r][PL]) for r in range(B)])
+
+            def truth(req, n):
+                s = streams[req.req_id]
+                return s[len(req.tokens):len(req.tokens) + n]
+
+            for _ in range(steps):
+                emitted = eng.step(truth)
+                log.append(([list(e) for e in emitted], [list(r.drafts) for r in eng.requests]))
+                for slot, r in enumerate(eng.requests):
+                    if r.num_tokens - r.num_prompt >= GL:
+                        rid = next_id[0]
+                        next_id[0] += 1
+                        eng.add_request(slot, rid, streams[rid][:PL], int(streams[rid][PL]))
+        except BaseException as e:     # noqa: BLE001 - a dead rank must not leave the other at the barrier
+            errors.append(e)
+            barrier.abort()
+            raise
+
+    rep_log, errs = [], []
+    rep = build(None)
+    drive(rep, rep_log, errs)
+    engines = [build((rk, 2, exchange_for(rk))) for rk in range(2)]
+    logs = [[], []]
+    threads = [threading.Thread(target=drive, args=(engines[rk], logs[rk], errs)) for rk in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errs, errs
+    assert len(rep_log) == steps and all(len(l) == steps for l in logs)
+    took_suffix = 0
+    for i in range(steps):
+        for rk in range(2):
+            assert logs[rk][i] == rep_log[i], (i, rk, logs[rk][i], rep_log[i])
+        took_suffix += sum(len(d) > 3 for d in rep_log[i][1])
+    assert took_suffix > 5                                  # suffix drafts (longer than the draft model's 3) were really scheduled
+    for rk in range(2):
+        held = set(engines[rk].suffix_cache.cached_prompt_ids())
+        want = {engines[rk].requests[s].req_id for s in range(B) if s % 2 == rk}
+        assert held == want, (rk, held, want)
+        st = engines[rk]._sharded.stats
+        assert st["queries_owned"] * 2 == st["queries_total"] and st["exchanges"] == steps
