@@ -228,7 +228,7 @@ class ArcticLSTMSpeculator:
     # The whole k-head draft as ONE HIP graph launch, like the reference's CUDA-graph cache (arctic_speculator.py:806-842, which
     # always replays a graph).  Built, tested bit-identical (test_lstm_graph_replay_equals_eager) and MEASURED (r04,
     # tools/microbench.py lstm, us per k = 3 draft, eager launches / graph replay): 32 rows, fp8 head 398.0 / 425.2; 64 rows,
-    # bf16 head 714.2 / 775.5; 8 rows 389.8 / 412.2 — the replay is 6-9 % SLOWER on ROCm 7.2: the draft is 13 kernels of which
+    # bf16 head 714.2 / 775.5; 8 rows 389.8 / 412.2 — the replay is 6-9 % SLOWER on ROCm 7.2: the draft is 9 kernels of which
     # six run 28-115 us, the host enqueues far ahead of the GPU either way, and a graph launch adds its own latency plus the
     # copies into and out of the static buffers.  So `use_graph` defaults to False here, against the reference's habit
     # (VERDICT r03 asked for True; the numbers say no).  Differences from the reference's cache when it is on, all
