@@ -102,6 +102,7 @@ _SIGNATURES = {
     "aic_ulysses_pack_pair": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "aic_ulysses_reorder_split_kv": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_int32), c_void_p]),
     "aic_debug_attn_trace": (c_int, [c_void_p, c_int]),
+    "aic_debug_attn_phase_trace": (c_int, [c_void_p, c_int]),
     "aic_debug_attn_layout": (c_int, [c_int, c_int]),
     "aic_debug_attn_sequential": (c_int, [c_int]),
     "aic_debug_attn_light": (c_int, [c_int]),

@@ -95,6 +95,10 @@ struct AttnParams {
   // (max, sum = 1) state of the FIRST partial of every row, so it is counted once however the range is split.
   int window;
   const float* sinks;
+  // debug (aic_debug_attn_phase_trace): per short-body workgroup (by * ptrace_stride + bx) eight 100 MHz timestamps —
+  // entry, request geometry known, first tile requested, first tile consumed, loop end, partials stored — or nullptr
+  int64_t* ptrace;
+  int ptrace_stride;
 };
 
 // first token of the range a request's rows can see, rounded down to a tile (0 without a window)
@@ -332,6 +336,9 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps loop control scalar
+  int64_t* ptr_ = P.ptrace ? P.ptrace + (static_cast<int64_t>(by) * P.ptrace_stride + bx) * 8 : nullptr;
+#define AIC_PSTAMP(i_) if (ptr_ && threadIdx.x == 0) ptr_[i_] = static_cast<int64_t>(__builtin_amdgcn_s_memrealtime());
+  AIC_PSTAMP(0)
   const int g = lane >> 4, c16 = lane & 15;
   const int Hkv = P.num_kv_heads, Hq = P.num_q_heads, G = Hq / Hkv;
   const int hgroups = Hkv / HPW;
@@ -353,6 +360,7 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
   const int n_rows = q_len * G;
   const int row0 = row_group * (MTQ * 16);
   if (row0 >= n_rows) return;
+  AIC_PSTAMP(1)
 
   const int n_parts = P.n_splits * R;
   const int part = by * R + range;
@@ -507,6 +515,7 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
     AIC_LOAD_V(t_begin, pages)
     AIC_LOAD_K(t_begin, pages)
     TilePages pages_next = tile_pages(t_begin + kTile);
+    AIC_PSTAMP(2)
 
     for (int tt = t_begin; tt < t_end; tt += kTile) {
       const int tn = tt + kTile;
@@ -580,6 +589,7 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
       }
     }
   }
+  AIC_PSTAMP(4)
 
 #undef AIC_LOAD_K
 #undef AIC_LOAD_V
@@ -627,6 +637,10 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
         mp[1] = l_run[mt];
         if (by == 0) mark_unused_parts(P, grow);
       }
+    }
+    AIC_PSTAMP(5)
+    if (ptr_ && threadIdx.x == 0) {
+      ptr_[6] = (static_cast<int64_t>(t_end - t_begin) << 32) | static_cast<uint32_t>(ctx);
     }
     return;
   }
@@ -709,6 +723,8 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
     }
   }
 }
+
+#undef AIC_PSTAMP
 
 // Host-partitioned calls (m_groups == 1): the short list holds requests of up to 32 query rows, and every workgroup
 // takes the one- or the two-row-tile form of the body by the rows of ITS request.  Most requests of a step have no draft
@@ -1347,6 +1363,8 @@ using namespace aic;
 
 static int64_t* g_attn_trace = nullptr;
 static int g_attn_trace_cap = 0;
+static int64_t* g_attn_ptrace = nullptr;   // aic_debug_attn_phase_trace
+static int g_attn_ptrace_cap = 0;
 static int g_long_splits = 0; // aic_debug_attn_long_splits: split count of the long-draft part of a mixed call (0 = the default)
 static int g_light_pct = 0;   // aic_debug_attn_light: weight of the light splits in percent (0 = the default, 100 = off)
 static int g_force_hpw = 0, g_force_splits = 0;   // aic_debug_attn_layout (tools/microbench.py sweeps); 0 = choose
@@ -1387,6 +1405,15 @@ extern "C" {
 int aic_debug_attn_trace(int64_t* buf, int capacity_wgs) {
   g_attn_trace = buf;
   g_attn_trace_cap = capacity_wgs;
+  return AIC_OK;
+}
+
+// debug: the next short-only launches of host-partitioned calls record eight timestamps per workgroup (entry, request
+// geometry known, first tile requested, first tile consumed, loop end, partials stored; [6] = tokens of the range << 32 |
+// context) into buf[workgroup][8] (device int64); nullptr switches it off
+int aic_debug_attn_phase_trace(int64_t* buf, int capacity_wgs) {
+  g_attn_ptrace = buf;
+  g_attn_ptrace_cap = capacity_wgs;
   return AIC_OK;
 }
 
@@ -1562,6 +1589,8 @@ int aic_verify_attention_win(const void* q, int64_t q_stride, const void* k_cach
   P.v_scale = v_scale;
   P.dbg = 0;
   P.trace = nullptr;
+  P.ptrace = nullptr;
+  P.ptrace_stride = 0;
   P.out = static_cast<uint16_t*>(out);
   P.out_stride = out_stride;
   P.direct = 0;
@@ -1703,7 +1732,12 @@ int aic_verify_attention_win(const void* q, int64_t q_stride, const void* k_cach
       P.m_groups = 1;
       P.n_items = n_short * hgroups_s;
       dim3 grid(static_cast<unsigned>((P.n_items + 7) / 8 * 8), n_splits, 1);
+      if (g_attn_ptrace && static_cast<int>(grid.x * grid.y) <= g_attn_ptrace_cap) {
+        P.ptrace = g_attn_ptrace;
+        P.ptrace_stride = static_cast<int>(grid.x);
+      }
       launch_short(mtq_short, hpw, grid);
+      P.ptrace = nullptr;
       if (!t_rec) profile_end(s);
     }
     if (n_long > 0 && short_first && (rc = launch_long()) != AIC_OK) return rc;

@@ -162,6 +162,9 @@ aic_suffix_tree* aic_sc_prompt_tree(aic_suffix_cache* c, int64_t req);
  * records per workgroup {start, end (100 MHz ticks), HW_ID | XCC_ID << 32, kind (0 short, 1 long, 2 pad)} into
  * buf[workgroup][4] (device int64, at least capacity_wgs rows).  NULL switches it off. */
 int aic_debug_attn_trace(int64_t* buf, int capacity_wgs);
+/* debug aid (tools/microbench.py phases): while `buf` is set, short-only launches of host-partitioned calls record per
+ * workgroup eight 100 MHz timestamps at the short body's phase boundaries into buf[workgroup][8] (device int64) */
+int aic_debug_attn_phase_trace(int64_t* buf, int capacity_wgs);
 /* debug aid: force the short attention body's kv heads per workgroup (4 / 2 / 1) and / or its cross-workgroup split count
  * for host-partitioned calls (0 = chosen by the library); every setting computes the same result. */
 int aic_debug_attn_layout(int heads_per_wg, int splits);

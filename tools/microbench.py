@@ -178,6 +178,55 @@ def attn_trace(n_short=59, n_long=5, q_short=1, q_long=33, ctx=4224, Hq=32, Hkv=
     print(f"  CUs used {len(per_cu)}; CUs with both kinds {len(both)}; per-CU mix {Counter(mix).most_common(6)}")
 
 
+def attn_phases(n_short=32, ctx=4224, kv8=False, Hq=32, Hkv=8, D=128, bs=16):
+    """Where a short-only launch's time goes per workgroup (aic_debug_attn_phase_trace): entry -> request geometry known ->
+    first tile requested -> [tile loop] -> partials stored, and when the workgroups start and end within the launch."""
+    B = n_short
+    nblk = (ctx + bs - 1) // bs
+    nb = B * nblk
+    if kv8:
+        raw = torch.randint(0, 256, (2, nb, bs, Hkv, D), dtype=torch.uint8, device=dev)
+        raw[(raw & 0x7f) == 0x7f] = 0x30
+        kv = raw.view(torch.float8_e4m3fn)
+        sc = torch.full((1,), 0.02, dtype=torch.float32, device=dev)
+        kw = dict(k_scale=sc, v_scale=sc)
+    else:
+        kv = torch.randn(2, nb, bs, Hkv, D, device=dev, dtype=torch.bfloat16)
+        kw = {}
+    # (a second cache to evict the first from the last-level cache between launches)
+    other = torch.randn(64 * 1024 * 1024, device=dev)
+    bt = torch.randperm(nb, device=dev).to(torch.int32).view(B, nblk)
+    q = torch.randn(B, Hq, D, device=dev, dtype=torch.bfloat16)
+    seq = torch.full((B,), ctx, dtype=torch.int32, device=dev)
+    qsl = torch.arange(B + 1, device=dev).to(torch.int32)
+    out = torch.empty_like(q)
+    rs = ops.split_requests([1] * B, Hq // Hkv, dev)
+    run = lambda: ops.verify_attention(q, kv[0], kv[1], bt, seq, qsl, 1, ctx, D ** -0.5, out=out, req_split=rs, **kw)
+    for _ in range(3):
+        run()
+    other.mul_(1.0001)
+    buf = torch.zeros((4096, 8), dtype=torch.int64, device=dev)
+    N.lib().aic_debug_attn_phase_trace(buf.data_ptr(), 4096)
+    run()
+    torch.cuda.synchronize()
+    N.lib().aic_debug_attn_phase_trace(None, 0)
+    t = buf.cpu().numpy()
+    t = t[t[:, 0] > 0]
+    us = lambda a: a / 100.0
+    t0 = t[:, 0].min()
+    tiles = (t[:, 6] >> 32) / 32.0
+    med = lambda a: float(np.median(us(a)))
+    print(f"attn-phases {'fp8' if kv8 else 'bf16'} cache, {n_short} requests x {ctx} tokens: {len(t)} workgroups, "
+          f"{np.median(tiles):.0f} tiles per wave; launch (first start -> last end) {us(t[:, 5].max() - t0):.1f} us")
+    print(f"   workgroup start after the first: median {med(t[:, 0] - t0):.2f} max {us((t[:, 0] - t0).max()):.2f} us")
+    print(f"   entry -> request geometry known (request list, lengths): median {med(t[:, 1] - t[:, 0]):.2f} us")
+    print(f"   geometry -> first tile requested (Q fragments, block table, K / V loads issued): {med(t[:, 2] - t[:, 1]):.2f} us")
+    print(f"   tile loop: median {med(t[:, 4] - t[:, 2]):.2f} us = {med(t[:, 4] - t[:, 2]) / np.median(tiles):.3f} us per 32-token tile "
+          f"(min {us((t[:, 4] - t[:, 2]).min()):.1f}, max {us((t[:, 4] - t[:, 2]).max()):.1f})")
+    print(f"   loop end -> partials stored: {med(t[:, 5] - t[:, 4]):.2f} us;  workgroup total median {med(t[:, 5] - t[:, 0]):.1f} us; "
+          f"last end - median end {us(t[:, 5].max() - np.median(t[:, 5])):.1f} us")
+
+
 def lstm(B, fp8=True):
     from arcticinference_amd.speculator import ArcticLSTMSpeculator, LSTMSpeculatorConfig, random_lstm_weights
     cfg = LSTMSpeculatorConfig(vocab_size=128256, input_hidden_dim=4096)
@@ -262,6 +311,11 @@ if __name__ == "__main__":
                 print(f"fp8 layout hpw={hpw} splits={sp}: ", end="")
                 attn_mix(B, 0, kv8=True)
         N.lib().aic_debug_attn_layout(0, 0)
+    if "phases" in what:      # in-kernel phase trace of the short body: where the per-call fixed cost sits
+        for kv8 in (False, True):
+            for n in (32, 64):
+                attn_phases(n, 4224, kv8)
+            attn_phases(32, 1056, kv8)
     if "ctxsweep" in what:    # short body over the context length: slope = streaming rate, intercept = fixed cost per call
         for kv8 in (False, True):
             for n in (32, 64):
