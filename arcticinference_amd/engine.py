@@ -671,7 +671,10 @@ class HotPathEngine:
             keep = pos < self.max_model_len                  # :701-707: the write is cut at max_model_len
             self.token_ids_cpu[np.repeat(live, n_emit)[keep], pos[keep]] = flat_emit[keep]
         if self.suffix_cache is not None:
-            self.suffix_cache.update_responses(req_ids, flat_emit, n_emit)   # _update_suffix_cache (:657-678)
+            if self._sharded is not None:
+                self._sharded.update(req_ids, flat_emit, n_emit)
+            else:
+                self.suffix_cache.update_responses(req_ids, flat_emit, n_emit)   # _update_suffix_cache (:657-678)
             _mark('host_suffix_update')
             # the tree mirror update + match kernels need nothing from the main stream (their input is the host
             # tree): on a side stream they run beside the LSTM draft instead of queueing behind it

@@ -99,6 +99,16 @@ class RankOwnedSuffix:
                 max_spec_tokens: np.ndarray, factor: np.ndarray, offset: np.ndarray, min_prob: np.ndarray):
         """Drafts for the requests (slots[i], req_ids[i]): this rank speculates for the ones it owns, one all-reduce brings
         everyone's.  Returns (tokens int32 [n, 32], n_tokens int32 [n], score float32 [n]) — identical on every rank."""
+        mat = self.local_matrix(slots, req_ids, flat_patterns, pattern_lens, max_spec_tokens, factor, offset, min_prob)
+        self.stats["exchanges"] += 1
+        return self.unpack(self.exchange(mat))
+
+    @staticmethod
+    def unpack(mat: np.ndarray):
+        return mat[:, 2:].copy(), mat[:, 0].copy(), mat[:, 1].copy().view(np.float32)
+
+    def local_matrix(self, slots, req_ids, flat_patterns, pattern_lens, max_spec_tokens, factor, offset, min_prob) -> np.ndarray:
+        """This rank's contribution to the step's result matrix: [n, RESULT_WIDTH] int32, zero rows for requests of others."""
         n = len(req_ids)
         mat = np.zeros((n, RESULT_WIDTH), np.int32)
         mine = np.asarray([i for i, s in enumerate(slots) if self.owns(s)], dtype=np.int64)
@@ -115,9 +125,7 @@ class RankOwnedSuffix:
             mat[mine, 0] = n_tok
             mat[mine, 1] = np.asarray(score, np.float32).view(np.int32)
             mat[mine, 2:2 + w] = toks[:, :w]
-        self.stats["exchanges"] += 1
-        mat = self.exchange(mat)
-        return mat[:, 2:].copy(), mat[:, 0].copy(), mat[:, 1].copy().view(np.float32)
+        return mat
 
     def _speculate_with_cache(self, req_ids, flat, lens, mst, fac, off, mpr):
         o_tok, _, o_n, o_sc, _ = self.cache.speculate_batch_arrays(req_ids, flat, lens, mst, fac, off, mpr,
@@ -148,3 +156,4 @@ def device_exchange(group, device) -> Callable[[np.ndarray], np.ndarray]:
         dist.all_reduce(t, group=group)
         return t.cpu().numpy()
     return exchange
+
