@@ -92,6 +92,11 @@ _SIGNATURES = {
     "aic_sc_speculate_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p]),
+    "aic_sc_speculate_batch_tree": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_void_p]),
+    "aic_debug_tree_mode_stats": (c_int, [c_void_p, c_void_p]),
+    "aic_debug_tree_mode_on_host": (c_int, [c_int]),
     "aic_sc_last_stats": (c_int, [c_void_p, POINTER(c_float), POINTER(c_int64), POINTER(c_int64)]),
     "aic_sc_last_timing": (c_int, [c_void_p, POINTER(c_float), POINTER(c_float)]),
     "aic_sc_global_tree": (c_void_p, [c_void_p]),

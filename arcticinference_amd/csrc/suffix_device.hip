@@ -13,6 +13,9 @@
 // cooperating only where the data is wide: comparing / emitting up to 64 edge tokens per step.
 // A second one-wave-per-query kernel reduces the per-start candidates with the reference's tie
 // rules (strict >, earlier start wins; prompt tree wins ties against the global tree).
+// Tree mode (_speculate_tree, suffix_tree.cc:226-274; the reference's simulator default, never the serving path) uses the
+// same decomposition with suffix_tree_spec_kernel: the walk is shared, the candidate is grown by a per-wave priority queue
+// over child lists mirrored in the host container's order (see the comment at that kernel).
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdlib>
@@ -67,6 +70,58 @@ __device__ __forceinline__ int32_t lookup_child(const TreeDesc& T, int32_t paren
   return -1;
 }
 
+// State of a position in a tree: `idx` tokens into the edge that leads into `node`.
+struct Cursor {
+  int32_t node, idx, node_len, node_count, node_best;
+  int64_t label;  // offset of the current edge's first token in T.tokens
+};
+
+__device__ __forceinline__ void load_node(const TreeDesc& T, int32_t node, Cursor& c) {
+  const int4 a = *reinterpret_cast<const int4*>(&T.nodes[node]);                // count,parent,seq_slot,start
+  const int4 b = *(reinterpret_cast<const int4*>(&T.nodes[node]) + 1);          // length,best,alive,pad
+  c.node = node;
+  c.node_count = uni(a.x);
+  c.node_best = uni(b.y);
+  const int2 sm = *reinterpret_cast<const int2*>(&T.seq_base[2 * uni(a.z)]);   // {region base, sequence length}
+  c.node_len = uni(b.x) != kOpenLength ? uni(b.x) : uni(sm.y) - uni(a.w);       // open leaf: to the sequence's end
+  c.label = static_cast<int64_t>(uni(sm.x)) + uni(a.w);
+}
+
+// walk the pattern suffix pat[s:n) down from the root (_match_pattern, suffix_tree.cc:167-188); wave-uniform result
+__device__ __forceinline__ bool match_walk(const TreeDesc& T, const int32_t* pat, int s, int n, int lane, Cursor& c) {
+  c.node = 0;
+  c.idx = 0;
+  c.node_len = 0;
+  c.node_count = 0;
+  c.node_best = -1;
+  c.label = 0;
+  int i = s;
+  while (i < n) {
+    if (c.idx >= c.node_len) {
+      const int32_t child = lookup_child(T, c.node, uni(pat[i]));
+      if (child < 0) return false;
+      load_node(T, child, c);
+      c.idx = 0;
+    }
+    // compare the rest of this edge with the pattern, 64 tokens per step across the lanes
+    const int m = min(c.node_len - c.idx, n - i);
+    bool same = true;
+    for (int j = lane; j < m; j += 64) same &= (T.tokens[c.label + c.idx + j] == pat[i + j]);
+    if (!__all(same)) return false;
+    c.idx += m;
+    i += m;
+  }
+  return true;
+}
+
+// budget (:149-152): float multiply-add without contraction, double +1e-6, truncate
+__device__ __forceinline__ int spec_budget_dev(int match_len, const QueryRec& Q, int cap) {
+  const float scaled = __fadd_rn(__fmul_rn(static_cast<float>(match_len), Q.factor), Q.offset);
+  int budget = static_cast<int>(static_cast<double>(scaled) + 1e-6);
+  budget = max(min(budget, Q.max_spec), 0);
+  return min(budget, cap);
+}
+
 // One wavefront per (query, tree, suffix start).
 __global__ void __launch_bounds__(256)
 suffix_match_kernel(const QueryRec* __restrict__ queries, const TreeDesc* __restrict__ trees,
@@ -91,76 +146,30 @@ suffix_match_kernel(const QueryRec* __restrict__ queries, const TreeDesc* __rest
   if (tree_idx >= 0 && s < n) {
     const TreeDesc T = trees[tree_idx];
     const int32_t* pat = patterns + uni(Q.pattern_off);
-
-    // ---- walk the pattern suffix pat[s:] down from the root (_match_pattern, :167-188) ----------
-    int32_t node = 0, idx = 0, node_len = 0, node_count = 0, node_best = -1;
-    int64_t label = 0;  // offset of the current edge's first token in T.tokens
-    bool ok = true;
-    int i = s;
-    while (i < n) {
-      if (idx >= node_len) {
-        const int32_t child = lookup_child(T, node, uni(pat[i]));
-        if (child < 0) {
-          ok = false;
-          break;
-        }
-        node = child;
-        const int4 a = *reinterpret_cast<const int4*>(&T.nodes[node]);                // count,parent,seq_slot,start
-        const int4 b = *(reinterpret_cast<const int4*>(&T.nodes[node]) + 1);          // length,best,alive,pad
-        node_count = uni(a.x);
-        node_best = uni(b.y);
-        const int2 sm = *reinterpret_cast<const int2*>(&T.seq_base[2 * uni(a.z)]);   // {region base, sequence length}
-        node_len = uni(b.x) != kOpenLength ? uni(b.x) : uni(sm.y) - uni(a.w);         // open leaf: to the sequence's end
-        label = static_cast<int64_t>(uni(sm.x)) + uni(a.w);
-        idx = 0;
-      }
-      // compare the rest of this edge with the pattern, 64 tokens per step across the lanes
-      const int m = min(node_len - idx, n - i);
-      bool same = true;
-      for (int j = lane; j < m; j += 64) same &= (T.tokens[label + idx + j] == pat[i + j]);
-      if (!__all(same)) {
-        ok = false;
-        break;
-      }
-      idx += m;
-      i += m;
-    }
-
-    if (ok) {
-      // ---- budget (:149-152): float multiply-add without contraction, double +1e-6, truncate ----
-      const int match_len = n - s;
-      const float scaled = __fadd_rn(__fmul_rn(static_cast<float>(match_len), Q.factor), Q.offset);
-      int budget = static_cast<int>(static_cast<double>(scaled) + 1e-6);
-      budget = max(min(budget, Q.max_spec), 0);
-      budget = min(budget, cap);
+    Cursor c;
+    if (match_walk(T, pat, s, n, lane, c)) {
+      const int budget = spec_budget_dev(n - s, Q, cap);
       const float min_prob = Q.min_prob;
 
       // ---- follow the most frequent continuation (_speculate_path, :190-224) --------------------
       float prob = 1.0f;
       const int64_t out = static_cast<int64_t>(item) * cap;
       while (nt < budget && prob >= min_prob) {
-        if (idx < node_len) {
-          const int m = min(node_len - idx, budget - nt);
+        if (c.idx < c.node_len) {
+          const int m = min(c.node_len - c.idx, budget - nt);
           for (int j = lane; j < m; j += 64) {
-            scr_tok[out + nt + j] = T.tokens[label + idx + j];
+            scr_tok[out + nt + j] = T.tokens[c.label + c.idx + j];
             scr_prob[out + nt + j] = prob;
           }
           for (int j = 0; j < m; ++j) score = __fadd_rn(score, prob);  // same order of f32 adds
           nt += m;
-          idx += m;
+          c.idx += m;
         } else {
-          if (node_best < 0) break;
-          const int32_t parent_count = node_count;
-          node = node_best;
-          const int4 a = *reinterpret_cast<const int4*>(&T.nodes[node]);
-          const int4 b = *(reinterpret_cast<const int4*>(&T.nodes[node]) + 1);
-          node_count = uni(a.x);
-          node_best = uni(b.y);
-          const int2 sm = *reinterpret_cast<const int2*>(&T.seq_base[2 * uni(a.z)]);
-          node_len = uni(b.x) != kOpenLength ? uni(b.x) : uni(sm.y) - uni(a.w);
-          label = static_cast<int64_t>(uni(sm.x)) + uni(a.w);
-          idx = 0;
-          prob = __fmul_rn(prob, __fdiv_rn(static_cast<float>(node_count), static_cast<float>(parent_count)));
+          if (c.node_best < 0) break;
+          const int32_t parent_count = c.node_count;
+          load_node(T, c.node_best, c);
+          c.idx = 0;
+          prob = __fmul_rn(prob, __fdiv_rn(static_cast<float>(c.node_count), static_cast<float>(parent_count)));
         }
       }
     }
@@ -168,6 +177,154 @@ suffix_match_kernel(const QueryRec* __restrict__ queries, const TreeDesc* __rest
   if (lane == 0) {
     scr_score[item] = score;
     scr_n[item] = nt;
+  }
+}
+
+// ---- tree-mode speculation (SuffixTree::_speculate_tree, suffix_tree.cc:226-274) -------------------------------------
+// Same decomposition — one wavefront per (query, tree, suffix start) — and the same walk; the candidate is then grown by a
+// priority queue on the estimated probability.  The reference's queue is std::priority_queue<HeapItem, vector, a.prob <
+// b.prob>: WHICH of several equally probable entries is popped first is decided by libstdc++'s heap algorithms
+// (std::push_heap = __push_heap, std::pop_heap = swap + __adjust_heap) and by the order in which the children were pushed
+// (the unordered_map's iteration order).  Both are reproduced here: the kid lists of the image are in container order
+// (suffix_host.hpp: serialize_kids), and heap_push / heap_pop below are those two algorithms statement by statement.
+// Every lane of the wave runs the same scalar program; the heap (kHeapCap entries of {prob bits, node, idx, parent}) lives
+// in a per-wave LDS region that all lanes read and write uniformly.  A node with more than kKidMax children, or a heap that
+// would outgrow its region, gives the item up (scr_n = -1): the host then evaluates that query (suffix_host.hpp: grow_tree).
+constexpr int kHeapCap = 256;
+
+__device__ __forceinline__ bool heap_less(const volatile int4* h, int a, float vprob) {   // comp(first[a], value)
+  return __int_as_float(h[a].x) < vprob;
+}
+// std::__push_heap(first, holeIndex, topIndex = 0, value)
+__device__ __forceinline__ void heap_sift_up(volatile int4* h, int hole, int4 value) {
+  const float vp = __int_as_float(value.x);
+  int parent = (hole - 1) / 2;
+  while (hole > 0 && heap_less(h, parent, vp)) {
+    const int4 e = make_int4(h[parent].x, h[parent].y, h[parent].z, h[parent].w);
+    h[hole].x = e.x; h[hole].y = e.y; h[hole].z = e.z; h[hole].w = e.w;
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  h[hole].x = value.x; h[hole].y = value.y; h[hole].z = value.z; h[hole].w = value.w;
+}
+// priority_queue::push: push_back, then std::push_heap
+__device__ __forceinline__ void heap_push(volatile int4* h, int& n, int4 value) {
+  heap_sift_up(h, n, value);
+  ++n;
+}
+// priority_queue::pop after top(): std::pop_heap (value = last, last = first, __adjust_heap(first, 0, len - 1, value)), pop_back
+__device__ __forceinline__ int4 heap_pop(volatile int4* h, int& n) {
+  const int4 top = make_int4(h[0].x, h[0].y, h[0].z, h[0].w);
+  const int len = n - 1;
+  if (len > 0) {
+    const int4 value = make_int4(h[len].x, h[len].y, h[len].z, h[len].w);
+    int hole = 0, second = 0;
+    while (second < (len - 1) / 2) {
+      second = 2 * (second + 1);
+      if (__int_as_float(h[second].x) < __int_as_float(h[second - 1].x)) --second;     // comp(first[second], first[second - 1])
+      const int4 e = make_int4(h[second].x, h[second].y, h[second].z, h[second].w);
+      h[hole].x = e.x; h[hole].y = e.y; h[hole].z = e.z; h[hole].w = e.w;
+      hole = second;
+    }
+    if ((len & 1) == 0 && second == (len - 2) / 2) {
+      second = 2 * (second + 1);
+      const int4 e = make_int4(h[second - 1].x, h[second - 1].y, h[second - 1].z, h[second - 1].w);
+      h[hole].x = e.x; h[hole].y = e.y; h[hole].z = e.z; h[hole].w = e.w;
+      hole = second - 1;
+    }
+    heap_sift_up(h, hole, value);     // (__push_heap with topIndex 0: the hole started at 0)
+  }
+  n = len;
+  return top;
+}
+
+__global__ void __launch_bounds__(256)
+suffix_tree_spec_kernel(const QueryRec* __restrict__ queries, const TreeDesc* __restrict__ trees,
+                        const int32_t* __restrict__ patterns, int n_starts, int cap, int n_items,
+                        float* __restrict__ scr_score, int32_t* __restrict__ scr_n, int32_t* __restrict__ scr_tok,
+                        float* __restrict__ scr_prob, int32_t* __restrict__ scr_par) {
+  __shared__ int4 heap_all[4][kHeapCap];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int item = uni(blockIdx.x * (blockDim.x >> 6) + wave);
+  if (item >= n_items) return;
+  volatile int4* heap = heap_all[wave];
+  const int per_q = 2 * n_starts;
+  const int qi = item / per_q;
+  const int rem = item - qi * per_q;
+  const int tr = rem / n_starts;
+  const int s = rem - tr * n_starts;
+
+  const QueryRec Q = queries[qi];
+  const int tree_idx = uni(tr == 0 ? Q.prompt_tree : Q.global_tree);
+  const int n = uni(Q.pattern_len);
+  float score = 0.0f;
+  int nt = 0;
+  bool gave_up = false;
+
+  if (tree_idx >= 0 && s < n) {
+    const TreeDesc T = trees[tree_idx];
+    const int32_t* pat = patterns + uni(Q.pattern_off);
+    Cursor c;
+    if (match_walk(T, pat, s, n, lane, c)) {
+      const int budget = spec_budget_dev(n - s, Q, cap);
+      const float min_prob = Q.min_prob;
+      const int64_t out = static_cast<int64_t>(item) * cap;
+      int hn = 0;
+      heap_push(heap, hn, make_int4(__float_as_int(1.0f), c.node, c.idx, -1));
+      while (nt < budget && hn > 0) {
+        const int4 it = heap_pop(heap, hn);
+        const float iprob = unif(__int_as_float(it.x));
+        const int32_t inode = uni(it.y), iidx = uni(it.z), ipar = uni(it.w);
+        Cursor k;
+        load_node(T, inode, k);
+        if (iidx < k.node_len) {
+          if (lane == 0) {
+            scr_tok[out + nt] = T.tokens[k.label + iidx];
+            scr_prob[out + nt] = iprob;
+            scr_par[out + nt] = ipar;
+          }
+          score = __fadd_rn(score, iprob);
+          if (hn >= kHeapCap) {
+            gave_up = true;
+            break;
+          }
+          heap_push(heap, hn, make_int4(__float_as_int(iprob), inode, iidx + 1, nt));
+          ++nt;
+        } else {
+          const int32_t* kb = T.kids + static_cast<int64_t>(inode) * kKidBlock;
+          const int nk = uni(kb[0]);
+          if (nk == kKidOverflow) {
+            gave_up = true;
+            break;
+          }
+          // lane j fetches child j and its count; the pushes then run in list order
+          int32_t my_child = -1, my_count = 0;
+          if (lane < nk) {
+            my_child = kb[1 + lane];
+            my_count = T.nodes[my_child].count;
+          }
+          for (int j = 0; j < nk; ++j) {
+            const int32_t child = uni(__shfl(my_child, j));
+            const int32_t ccount = uni(__shfl(my_count, j));
+            // item.prob * child->count / static_cast<float>(item.node->count)   (float * int -> float, then / float)
+            const float p = __fdiv_rn(__fmul_rn(iprob, static_cast<float>(ccount)), static_cast<float>(k.node_count));
+            if (p >= min_prob) {
+              if (hn >= kHeapCap) {
+                gave_up = true;
+                break;
+              }
+              heap_push(heap, hn, make_int4(__float_as_int(p), child, 0, ipar));
+            }
+          }
+          if (gave_up) break;
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+    scr_score[item] = score;
+    scr_n[item] = gave_up ? -1 : nt;
   }
 }
 
@@ -179,17 +336,19 @@ suffix_select_kernel(const QueryRec* __restrict__ queries, int n_starts, int cap
                      int32_t* __restrict__ out_n, float* __restrict__ out_score,
                      int32_t* __restrict__ out_match, int32_t* __restrict__ out_tok,
                      float* __restrict__ out_prob, int32_t* __restrict__ done_counter, int32_t* done_flag,
-                     int32_t epoch) {
+                     int32_t epoch, const int32_t* __restrict__ scr_par, int32_t* __restrict__ out_par) {
   const int qi = blockIdx.x;
   const int lane = threadIdx.x;
   const int n = queries[qi].pattern_len;
   float win_score = 0.0f;
   int win_item = -1, win_s = 0;
+  bool gave_up = false;      // tree mode: an item of this query was given back to the host (scr_n = -1): so is the query
   for (int tr = 0; tr < 2; ++tr) {
     const int base = (qi * 2 + tr) * n_starts;
     float my = 0.0f;
     int my_s = 0x7fffffff;
     for (int s = lane; s < n_starts; s += 64) {
+      if (scr_par != nullptr && scr_n[base + s] < 0) gave_up = true;
       const float v = scr_score[base + s];
       if (v > my) {  // strict: the earliest start (longest match) of equal scores stays
         my = v;
@@ -212,13 +371,16 @@ suffix_select_kernel(const QueryRec* __restrict__ queries, int n_starts, int cap
     }
   }
   int cnt = 0;
-  if (win_item >= 0) {
+  gave_up = __any(gave_up);
+  if (win_item >= 0 && !gave_up) {
     cnt = scr_n[win_item];
     for (int j = lane; j < cnt; j += 64) {
       out_tok[static_cast<int64_t>(qi) * cap + j] = scr_tok[static_cast<int64_t>(win_item) * cap + j];
       out_prob[static_cast<int64_t>(qi) * cap + j] = scr_prob[static_cast<int64_t>(win_item) * cap + j];
+      if (out_par != nullptr) out_par[static_cast<int64_t>(qi) * cap + j] = scr_par[static_cast<int64_t>(win_item) * cap + j];
     }
   }
+  if (gave_up) cnt = -1;
   if (lane == 0) {
     out_n[qi] = cnt;
     out_score[qi] = win_score;
@@ -284,6 +446,8 @@ struct TreeImage {
   int32_t* seq_base = nullptr;
   size_t seq_cap = 0;
   size_t seq_synced = 0;  // seq_base entries already mirrored
+  int32_t* kids = nullptr;   // [kids_cap / kKidBlock][kKidBlock]: child lists (trees that were asked for tree mode)
+  size_t kids_cap = 0;       // words
 };
 
 class Mirror;
@@ -490,6 +654,26 @@ class Mirror {
       }
       add_job(I.seq_base, off, ioff, 0, static_cast<int32_t>(d), 2);
     }
+    // child lists in container order (tree-mode speculation): only for trees that were ever asked for it
+    if (H.track_kids()) {
+      const bool first_time = I.kids == nullptr;
+      if ((rc = grow(pool, &I.kids, &I.kids_cap, n_nodes * kKidBlock, &moved)) != AIC_OK) return rc;
+      if (moved || full || first_time) {
+        if ((rc = reserve(n_nodes * kKidBlock, &off)) != AIC_OK) return rc;
+        for (size_t k = 0; k < n_nodes; ++k) H.serialize_kids(static_cast<int32_t>(k), at(off) + k * kKidBlock);
+        add_job(I.kids, off, -1, 0, static_cast<int32_t>(n_nodes), kKidBlock);
+      } else if (!H.dirty_kids().empty()) {
+        const size_t d = H.dirty_kids().size();
+        if ((rc = reserve(d * kKidBlock, &off)) != AIC_OK) return rc;
+        if ((rc = reserve(d, &ioff)) != AIC_OK) return rc;
+        for (size_t k = 0; k < d; ++k) {
+          const int32_t ni = H.dirty_kids()[k];
+          H.serialize_kids(ni, at(off) + k * kKidBlock);
+          at(ioff)[k] = ni;
+        }
+        add_job(I.kids, off, ioff, 0, static_cast<int32_t>(d), kKidBlock);
+      }
+    }
     H.clear_dirty();
 
     TreeDesc d;
@@ -499,17 +683,20 @@ class Mirror {
     d.seq_base = I.seq_base;
     d.hash_mask = H.hash_mask();
     d.n_nodes = static_cast<int32_t>(n_nodes);
-    d.pad0 = d.pad1 = 0;
+    d.kids = I.kids;
     *desc_index = static_cast<int>(descs_.size());
     descs_.push_back(d);
     return AIC_OK;
   }
 
   // Runs the batch: blob H2D, delta apply, match + select, results D2H, stream sync.
+  // `out_parents` != nullptr: TREE mode (suffix_tree_spec_kernel; every tree of the batch must carry kid lists) — out_n[i] = -1
+  // marks a query the device gave back (a node with more than kKidMax children, or a heap beyond kHeapCap)
   int run(const std::vector<QueryRec>& queries, const std::vector<int32_t>& pattern_pool, int n_starts, int cap,
           int32_t* out_tokens, float* out_probs, int32_t* out_n, float* out_score, int32_t* out_match,
-          hipStream_t stream) {
-    const int rc = run_batch(queries, pattern_pool, n_starts, cap, out_tokens, out_probs, out_n, out_score, out_match, stream);
+          hipStream_t stream, int32_t* out_parents = nullptr) {
+    const int rc = run_batch(queries, pattern_pool, n_starts, cap, out_tokens, out_probs, out_n, out_score, out_match, stream,
+                             out_parents);
     if (rc != AIC_OK) return fail_batch(rc);
     batch_trees_.clear();   // the deltas are on the device (stream synchronised): the sync state stands
     return AIC_OK;
@@ -517,8 +704,9 @@ class Mirror {
 
   int run_batch(const std::vector<QueryRec>& queries, const std::vector<int32_t>& pattern_pool, int n_starts, int cap,
                 int32_t* out_tokens, float* out_probs, int32_t* out_n, float* out_score, int32_t* out_match,
-                hipStream_t stream) {
+                hipStream_t stream, int32_t* out_parents) {
     const int nq = static_cast<int>(queries.size());
+    const bool tree_mode = out_parents != nullptr;
     int rc;
     int64_t q_off, p_off, d_off, j_off;
     // fix pattern offsets relative to the blob once the pool position is known
@@ -541,8 +729,8 @@ class Mirror {
     }
     // scratch: per item {score, n} + cap tokens + cap probs; outputs per query
     const size_t n_items = static_cast<size_t>(nq) * 2 * n_starts;
-    const size_t scr_words = n_items * 2 + n_items * cap * 2;
-    const size_t out_words = static_cast<size_t>(nq) * (3 + 2 * static_cast<size_t>(cap));
+    const size_t scr_words = n_items * 2 + n_items * cap * (tree_mode ? 3 : 2);
+    const size_t out_words = static_cast<size_t>(nq) * (3 + (tree_mode ? 3 : 2) * static_cast<size_t>(cap));
     const size_t scr_bytes = (scr_words + out_words + 16) * 4;
     if (scr_bytes > dscr_cap_) {
       if (dscr_) AIC_HIP_TRY(hipFree(dscr_));
@@ -618,12 +806,14 @@ class Mirror {
     int32_t* scr_n = dscr_ + n_items;
     int32_t* scr_tok = dscr_ + 2 * n_items;
     float* scr_prob = reinterpret_cast<float*>(dscr_ + 2 * n_items + n_items * cap);
+    int32_t* scr_par = tree_mode ? dscr_ + 2 * n_items + 2 * n_items * cap : nullptr;
     int32_t* d_out = staged ? dscr_ + scr_words : pin_out_dev;
     int32_t* o_n = d_out;
     float* o_score = reinterpret_cast<float*>(d_out + nq);
     int32_t* o_match = d_out + 2 * nq;
     int32_t* o_tok = d_out + 3 * nq;
     float* o_prob = reinterpret_cast<float*>(d_out + 3 * nq + static_cast<size_t>(nq) * cap);
+    int32_t* o_par = tree_mode ? d_out + 3 * nq + 2 * static_cast<size_t>(nq) * cap : nullptr;
     int32_t* flag_host = pin_out_ + pin_out_cap_ / 4 - 16;       // last 64 bytes of the result block
     int32_t* flag_dev = staged ? nullptr : pin_out_dev + pin_out_cap_ / 4 - 16;
     epoch_ = epoch_ == 0x7ffffff0 ? 1 : epoch_ + 1;
@@ -631,14 +821,21 @@ class Mirror {
     AIC_HIP_TRY(hipEventRecord(ev0_, stream));
     const int waves_per_block = 4;
     const int blocks = static_cast<int>((n_items + waves_per_block - 1) / waves_per_block);
-    hipLaunchKernelGGL(suffix_match_kernel, dim3(blocks), dim3(64 * waves_per_block), 0, stream,
-                       reinterpret_cast<const QueryRec*>(dblob_ + q_off),
-                       reinterpret_cast<const TreeDesc*>(dblob_ + d_off), dblob_ + p_off, n_starts, cap,
-                       static_cast<int>(n_items), scr_score, scr_n, scr_tok, scr_prob);
+    if (tree_mode)
+      hipLaunchKernelGGL(suffix_tree_spec_kernel, dim3(blocks), dim3(64 * waves_per_block), 0, stream,
+                         reinterpret_cast<const QueryRec*>(dblob_ + q_off),
+                         reinterpret_cast<const TreeDesc*>(dblob_ + d_off), dblob_ + p_off, n_starts, cap,
+                         static_cast<int>(n_items), scr_score, scr_n, scr_tok, scr_prob, scr_par);
+    else
+      hipLaunchKernelGGL(suffix_match_kernel, dim3(blocks), dim3(64 * waves_per_block), 0, stream,
+                         reinterpret_cast<const QueryRec*>(dblob_ + q_off),
+                         reinterpret_cast<const TreeDesc*>(dblob_ + d_off), dblob_ + p_off, n_starts, cap,
+                         static_cast<int>(n_items), scr_score, scr_n, scr_tok, scr_prob);
     if ((rc = launch_status("suffix_match_kernel")) != AIC_OK) return rc;
     hipLaunchKernelGGL(suffix_select_kernel, dim3(nq), dim3(64), 0, stream,
                        reinterpret_cast<const QueryRec*>(dblob_ + q_off), n_starts, cap, scr_score, scr_n,
-                       scr_tok, scr_prob, o_n, o_score, o_match, o_tok, o_prob, done_counter_, flag_dev, epoch_);
+                       scr_tok, scr_prob, o_n, o_score, o_match, o_tok, o_prob, done_counter_, flag_dev, epoch_,
+                       static_cast<const int32_t*>(scr_par), o_par);
     if ((rc = launch_status("suffix_select_kernel")) != AIC_OK) return rc;
     AIC_HIP_TRY(hipEventRecord(ev1_, stream));
     if (staged) {
@@ -673,14 +870,15 @@ class Mirror {
     const int32_t* h_match = pin_out_ + 2 * nq;
     const int32_t* h_tok = pin_out_ + 3 * nq;
     const float* h_prob = reinterpret_cast<const float*>(pin_out_ + 3 * nq + static_cast<size_t>(nq) * cap);
+    const int32_t* h_par = pin_out_ + 3 * nq + 2 * static_cast<size_t>(nq) * cap;
     for (int i = 0; i < nq; ++i) {
       out_n[i] = h_n[i];
       out_score[i] = h_score[i];
       out_match[i] = h_match[i];
-      std::memcpy(out_tokens + static_cast<size_t>(i) * cap, h_tok + static_cast<size_t>(i) * cap,
-                  static_cast<size_t>(h_n[i]) * 4);
-      std::memcpy(out_probs + static_cast<size_t>(i) * cap, h_prob + static_cast<size_t>(i) * cap,
-                  static_cast<size_t>(h_n[i]) * 4);
+      const size_t cnt = h_n[i] > 0 ? static_cast<size_t>(h_n[i]) : 0;
+      std::memcpy(out_tokens + static_cast<size_t>(i) * cap, h_tok + static_cast<size_t>(i) * cap, cnt * 4);
+      std::memcpy(out_probs + static_cast<size_t>(i) * cap, h_prob + static_cast<size_t>(i) * cap, cnt * 4);
+      if (tree_mode) std::memcpy(out_parents + static_cast<size_t>(i) * cap, h_par + static_cast<size_t>(i) * cap, cnt * 4);
     }
     return AIC_OK;
   }
@@ -724,6 +922,7 @@ static void release_image(aic_suffix_tree* t) {
   t->pool->put(I.hash, I.hash_cap * sizeof(HashSlot));
   t->pool->put(I.tokens, I.tokens_cap * sizeof(int32_t));
   t->pool->put(I.seq_base, I.seq_cap * sizeof(int32_t));
+  t->pool->put(I.kids, I.kids_cap * sizeof(int32_t));
   I = TreeImage();
 }
 
@@ -757,6 +956,9 @@ struct aic_suffix_cache {
 };
 
 using namespace aic;
+
+static int64_t g_tree_mode_device = 0, g_tree_mode_fallbacks = 0;
+static bool g_tree_mode_on_host = false;
 
 extern "C" {
 
@@ -794,7 +996,9 @@ int aic_st_speculate(aic_suffix_tree* t, const int32_t* pattern, int n, int max_
     pattern += n - depth;
     n = depth;
   }
-  if (use_tree_spec) {
+  // tree mode without a device (CPU tests of the host trees), or when the device gives the query back: the host's own
+  // priority-queue expansion (suffix_host.hpp: grow_tree)
+  auto host_tree_mode = [&]() -> int {
     HostCandidate c = t->host.speculate_tree(pattern, n, max_spec_tokens, factor, offset, min_prob);
     const int m = std::min<int>(static_cast<int>(c.token_ids.size()), cap);
     for (int i = 0; i < m; ++i) {
@@ -805,7 +1009,8 @@ int aic_st_speculate(aic_suffix_tree* t, const int32_t* pattern, int n, int max_
     *out_score = c.score;
     *out_match_len = c.match_len;
     return m;
-  }
+  };
+  if (use_tree_spec && (aic_device_count() <= 0 || g_tree_mode_on_host)) return host_tree_mode();
   AIC_NEED_DEVICE();
   if (!t->own) {
     t->own.reset(new Mirror());
@@ -813,6 +1018,10 @@ int aic_st_speculate(aic_suffix_tree* t, const int32_t* pattern, int n, int max_
   }
   DevPool& pool = t->pool ? *t->pool : *t->own_pool;
   Mirror& mir = *t->own;
+  if (use_tree_spec) {
+    t->join_build();
+    t->host.enable_kid_tracking();
+  }
   mir.begin();
   int di = -1;
   int rc = mir.add_tree(t, pool, &di);
@@ -828,23 +1037,43 @@ int aic_st_speculate(aic_suffix_tree* t, const int32_t* pattern, int n, int max_
   q.min_prob = min_prob;
   std::vector<QueryRec> qs(1, q);
   std::vector<int32_t> pool_words(pattern, pattern + n);
-  const int kcap = std::max(std::min(std::max(max_spec_tokens, 0), depth), 1);
-  std::vector<int32_t> toks(kcap);
+  // a path candidate cannot be longer than max_depth; a tree candidate has branches and is bounded by max_spec_tokens only
+  const int kcap = use_tree_spec ? std::max(max_spec_tokens, 1) : std::max(std::min(std::max(max_spec_tokens, 0), depth), 1);
+  std::vector<int32_t> toks(kcap), pars(kcap);
   std::vector<float> probs(kcap);
   int32_t cnt = 0, mlen = 0;
   float score = 0.0f;
   rc = mir.run(qs, pool_words, n, kcap, toks.data(), probs.data(), &cnt, &score, &mlen,
-               static_cast<hipStream_t>(stream));
+               static_cast<hipStream_t>(stream), use_tree_spec ? pars.data() : nullptr);
   if (rc != AIC_OK) return rc;
+  if (use_tree_spec) {
+    if (cnt < 0) {                       // given back by the device
+      ++g_tree_mode_fallbacks;
+      return host_tree_mode();
+    }
+    ++g_tree_mode_device;
+  }
   const int m = std::min<int>(cnt, cap);
   for (int i = 0; i < m; ++i) {
     out_tokens[i] = toks[i];
-    if (out_parents) out_parents[i] = i - 1;
+    if (out_parents) out_parents[i] = use_tree_spec ? pars[i] : i - 1;
     out_probs[i] = probs[i];
   }
   *out_score = score;
   *out_match_len = mlen;
   return m;
+}
+
+// tree-mode bookkeeping / switches (tests): queries answered by the device, queries the device gave back to the host;
+// aic_debug_tree_mode_on_host(1) sends every tree-mode query to the host trees (the A/B reference)
+int aic_debug_tree_mode_stats(int64_t* on_device, int64_t* given_back) {
+  if (on_device) *on_device = g_tree_mode_device;
+  if (given_back) *given_back = g_tree_mode_fallbacks;
+  return AIC_OK;
+}
+int aic_debug_tree_mode_on_host(int on) {
+  g_tree_mode_on_host = on != 0;
+  return AIC_OK;
 }
 
 int aic_st_export(aic_suffix_tree* t, int32_t* n_nodes, int32_t* n_slots, int32_t* n_tokens, int32_t* n_seq_slots,
@@ -1032,11 +1261,11 @@ int aic_sc_update_responses(aic_suffix_cache* c, int n_req, const int64_t* reqs,
   return AIC_OK;
 }
 
-int aic_sc_speculate_batch(aic_suffix_cache* c, int n_query, const int64_t* reqs, const int32_t* patterns,
-                           const int32_t* pattern_lens, const int32_t* max_spec_tokens, const float* factor,
-                           const float* offset, const float* min_prob, const int32_t* use_prompt, int cap,
-                           int32_t* out_tokens, float* out_probs, int32_t* out_n, float* out_score,
-                           int32_t* out_match_len, void* stream) {
+static int sc_speculate_batch(aic_suffix_cache* c, int n_query, const int64_t* reqs, const int32_t* patterns,
+                              const int32_t* pattern_lens, const int32_t* max_spec_tokens, const float* factor,
+                              const float* offset, const float* min_prob, const int32_t* use_prompt, int cap,
+                              int32_t* out_tokens, float* out_probs, int32_t* out_n, float* out_score,
+                              int32_t* out_match_len, void* stream, int32_t* out_parents) {
   AIC_REQUIRE(c && n_query >= 0 && cap > 0, "bad arguments to aic_sc_speculate_batch");
   if (n_query == 0) return AIC_OK;
   AIC_REQUIRE(reqs && patterns && pattern_lens && max_spec_tokens && factor && offset && min_prob && use_prompt &&
@@ -1056,6 +1285,8 @@ int aic_sc_speculate_batch(aic_suffix_cache* c, int n_query, const int64_t* reqs
   AIC_NEED_DEVICE();
   Mirror& mir = c->mirror;
   const auto t_begin = std::chrono::steady_clock::now();
+  const bool tree_mode = out_parents != nullptr;
+  if (tree_mode) c->global->host.enable_kid_tracking();      // (its first mirror after this uploads every child list)
   mir.begin();
   int rc, gdesc = -1;
   if ((rc = mir.add_tree(c->global.get(), c->pool, &gdesc)) != AIC_OK) return mir.fail_batch(rc);
@@ -1086,7 +1317,12 @@ int aic_sc_speculate_batch(aic_suffix_cache* c, int n_query, const int64_t* reqs
       auto it = pdesc.find(reqs[i]);
       if (it == pdesc.end()) {
         int di = -1;
-        if ((rc = mir.add_tree(c->prompts[reqs[i]].get(), c->pool, &di)) != AIC_OK) return mir.fail_batch(rc);
+        aic_suffix_tree* pt = c->prompts[reqs[i]].get();
+        if (tree_mode) {
+          pt->join_build();
+          pt->host.enable_kid_tracking();
+        }
+        if ((rc = mir.add_tree(pt, c->pool, &di)) != AIC_OK) return mir.fail_batch(rc);
         it = pdesc.emplace(reqs[i], di).first;
       }
       q.prompt_tree = it->second;
@@ -1095,11 +1331,36 @@ int aic_sc_speculate_batch(aic_suffix_cache* c, int n_query, const int64_t* reqs
   }
   const auto t_built = std::chrono::steady_clock::now();
   rc = mir.run(qs, pool_words, n_starts, cap, out_tokens, out_probs, out_n, out_score, out_match_len,
-               static_cast<hipStream_t>(stream));
+               static_cast<hipStream_t>(stream), out_parents);
   const auto t_done = std::chrono::steady_clock::now();
   c->last_build_us = std::chrono::duration<float, std::micro>(t_built - t_begin).count();
   c->last_device_us = std::chrono::duration<float, std::micro>(t_done - t_built).count();
+  if (rc == AIC_OK && tree_mode)
+    for (int i = 0; i < n_query; ++i) (out_n[i] < 0 ? g_tree_mode_fallbacks : g_tree_mode_device) += 1;
   return rc;
+}
+
+int aic_sc_speculate_batch(aic_suffix_cache* c, int n_query, const int64_t* reqs, const int32_t* patterns,
+                           const int32_t* pattern_lens, const int32_t* max_spec_tokens, const float* factor,
+                           const float* offset, const float* min_prob, const int32_t* use_prompt, int cap,
+                           int32_t* out_tokens, float* out_probs, int32_t* out_n, float* out_score,
+                           int32_t* out_match_len, void* stream) {
+  return sc_speculate_batch(c, n_query, reqs, patterns, pattern_lens, max_spec_tokens, factor, offset, min_prob, use_prompt,
+                            cap, out_tokens, out_probs, out_n, out_score, out_match_len, stream, nullptr);
+}
+
+// Tree-mode speculation for a batch (use_tree_spec = True, suffix_tree.cc:245-274) on the device: as above, plus
+// out_parents [n_query][cap].  out_n[i] = -1: the device gave query i back (a node with more than 15 children on its way,
+// or a priority queue beyond 256 entries) — the caller evaluates it on the host trees (aic_st_speculate on
+// aic_sc_prompt_tree / aic_sc_global_tree with aic_debug_tree_mode_on_host, or SuffixCache._speculate_tree_mode).
+int aic_sc_speculate_batch_tree(aic_suffix_cache* c, int n_query, const int64_t* reqs, const int32_t* patterns,
+                                const int32_t* pattern_lens, const int32_t* max_spec_tokens, const float* factor,
+                                const float* offset, const float* min_prob, const int32_t* use_prompt, int cap,
+                                int32_t* out_tokens, int32_t* out_parents, float* out_probs, int32_t* out_n,
+                                float* out_score, int32_t* out_match_len, void* stream) {
+  AIC_REQUIRE(out_parents, "aic_sc_speculate_batch_tree needs out_parents");
+  return sc_speculate_batch(c, n_query, reqs, patterns, pattern_lens, max_spec_tokens, factor, offset, min_prob, use_prompt,
+                            cap, out_tokens, out_probs, out_n, out_score, out_match_len, stream, out_parents);
 }
 
 // where the last aic_sc_speculate_batch spent its wall time: collecting the trees' deltas and the queries on the host,

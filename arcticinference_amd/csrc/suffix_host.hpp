@@ -45,6 +45,15 @@ struct HostCandidate {
 
 constexpr int32_t kOpenLength = -1;  // NodeRec::length of an open leaf (also read by the matcher kernels)
 
+// Tree-mode speculation on the device (suffix_tree.cc:245-274) expands EVERY child of a node in the container's iteration
+// order, so trees that are asked for it mirror one fixed block per node: [n, child_0 .. child_{n-1}] in iteration order,
+// n = kKidOverflow for a node with more than kKidMax children (the device gives such a query back to the host).  Opt-in
+// per tree (enable_kid_tracking(), switched on by the first tree-mode query): serving never asks for tree mode
+// (model_runner.py:734-740) and pays nothing.
+constexpr int kKidBlock = 16;
+constexpr int kKidMax = kKidBlock - 1;
+constexpr int32_t kKidOverflow = -2;
+
 class HostTree {
  public:
   using KidMap = std::unordered_map<int, int32_t>;
@@ -135,6 +144,7 @@ class HostTree {
           mark_node(ci);
           const int first = tok_at(C.seq_slot, C.start);
           (*kids_[pi])[first] = ci;  // existing key, value overwrite: iteration order untouched
+          mark_kids(pi);
           hash_set(pi, first, ci);
           if (pi != 0 && recs_[pi].best == ni) {
             recs_[pi].best = ci;  // same slot in the order, same count
@@ -159,6 +169,7 @@ class HostTree {
             KidMap& km = *kids_[ni];
             km[first] = ci;   // insert the new key first ...
             km.erase(token);  // ... then drop the old one (same order of operations as the reference)
+            mark_kids(ni);
             hash_erase(ni, token);
             hash_insert(ni, first, ci);
           }
@@ -184,8 +195,10 @@ class HostTree {
           const int second = tok_at(C.seq_slot, C.start + 1);
           kids_[mid] = new KidMap();
           (*kids_[mid])[second] = ci;
+          mark_kids(mid);
           hash_insert(mid, second, ci);
           (*kids_[ni])[token] = mid;  // existing key, value overwrite
+          mark_kids(ni);
           hash_set(ni, token, mid);
           C.parent = mid;
           C.start += 1;
@@ -285,6 +298,23 @@ class HostTree {
   std::vector<int32_t>& dirty_nodes() { return dirty_nodes_; }
   std::vector<int32_t>& dirty_slots() { return dirty_slots_; }
   bool hash_rebuilt() const { return hash_rebuilt_; }
+  // ---- child lists for tree-mode speculation on the device (kKidBlock words per node) ----------------------
+  bool track_kids() const { return track_kids_; }
+  void enable_kid_tracking() { track_kids_ = true; }       // (the first mirror after this uploads every node's list)
+  std::vector<int32_t>& dirty_kids() { return dirty_kids_; }
+  void serialize_kids(int32_t p, int32_t* out) const {
+    const KidMap* km = kids_[p];
+    const size_t n = km ? km->size() : 0;
+    for (int j = 1; j < kKidBlock; ++j) out[j] = -1;
+    if (n > static_cast<size_t>(kKidMax)) {
+      out[0] = kKidOverflow;
+      return;
+    }
+    out[0] = static_cast<int32_t>(n);
+    int j = 1;
+    if (km)
+      for (const auto& kv : *km) out[j++] = kv.second;     // the container's iteration order (suffix_tree.cc:263)
+  }
   void clear_dirty() {
     for (int32_t i : dirty_nodes_) node_dirty_[i] = 0;
     dirty_nodes_.clear();
@@ -292,6 +322,8 @@ class HostTree {
     dirty_slots_.clear();
     for (int32_t i : dirty_seqs_) seq_dirty_[i] = 0;
     dirty_seqs_.clear();
+    for (int32_t i : dirty_kids_) kid_dirty_[i] = 0;
+    dirty_kids_.clear();
     hash_rebuilt_ = false;
   }
   // Reserve (or enlarge) the token-pool region of a sequence so that `need` tokens fit.
@@ -398,6 +430,7 @@ class HostTree {
     }
     recs_[i].alive = 1;
     mark_node(i);
+    mark_kids(i);      // (a reused slot starts with an empty child list)
     return i;
   }
   void release_node(int32_t i) {
@@ -405,12 +438,21 @@ class HostTree {
     kids_[i] = nullptr;
     recs_[i] = blank();
     mark_node(i);
+    mark_kids(i);
     free_.push_back(i);
   }
   void mark_node(int32_t i) {
     if (!node_dirty_[i]) {
       node_dirty_[i] = 1;
       dirty_nodes_.push_back(i);
+    }
+  }
+  void mark_kids(int32_t i) {
+    if (!track_kids_) return;
+    if (static_cast<size_t>(i) >= kid_dirty_.size()) kid_dirty_.resize(recs_.size(), 0);
+    if (!kid_dirty_[i]) {
+      kid_dirty_[i] = 1;
+      dirty_kids_.push_back(i);
     }
   }
 
@@ -443,6 +485,7 @@ class HostTree {
     KidMap& km = *kids_[p];
     const size_t buckets = km.bucket_count();
     km.emplace(token, leaf);
+    mark_kids(p);
     hash_insert(p, token, leaf);
     if (p == 0) return;  // nobody ever asks for the root's most frequent child
     const int32_t b = recs_[p].best;
@@ -591,6 +634,9 @@ class HostTree {
   std::vector<int32_t> free_;
   std::vector<uint8_t> node_dirty_;
   std::vector<int32_t> dirty_nodes_;
+  bool track_kids_ = false;
+  std::vector<uint8_t> kid_dirty_;
+  std::vector<int32_t> dirty_kids_;
 
   std::vector<HashSlot> slots_;
   std::vector<uint8_t> slot_dirty_;

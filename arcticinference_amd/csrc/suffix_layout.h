@@ -5,6 +5,8 @@
 //   hash    : HashSlot[n_slots]     16 B each, open addressing, linear probing, n_slots = 2^k
 //   tokens  : int32[...]            every sequence owns one contiguous region
 //   seq_base: int32[2 * n_seq_slots]  {offset of that region, current length of the sequence} per slot
+//   kids    : int32[n_nodes][16]    (only for trees that were asked for tree-mode speculation) {n, child x 15} per node,
+//                                   children in the host container's iteration order, n = -2: more than 15 children
 //
 // An edge label is (seq_slot, start, length): token j of the edge is
 // tokens[seq_base[2 * seq_slot] + start + j]  (reference: Node{seq_id,start,length}, suffix_tree.h:24-44).
@@ -60,9 +62,9 @@ struct TreeDesc {
   const int32_t* seq_base;
   uint32_t hash_mask;
   int32_t n_nodes;
-  int32_t pad0;
-  int32_t pad1;
+  const int32_t* kids;   // [n_nodes][kKidBlock] child lists in container order (tree-mode speculation) or nullptr
 };
+static_assert(sizeof(TreeDesc) == 48, "TreeDesc is copied through the int32 blob");
 
 // One speculation query (one request of the engine step).
 struct QueryRec {

@@ -230,16 +230,48 @@ class SuffixCache:
                                     [min_token_prob], [use_cached_prompt])[0]
 
     def _speculate_tree_mode(self, req_id, pattern, max_spec_tokens, factor, offset, min_prob, use_prompt):
-        # tree candidates are an offline-simulator feature of the reference; evaluated by the host trees
+        """use_tree_spec = True (SuffixTree::_speculate_tree, suffix_tree.cc:226-274; the reference's simulator default, never
+        the serving path): on the device since r04 (aic_sc_speculate_batch_tree: both trees, every suffix start, a priority
+        queue per wave that reproduces std::priority_queue's order); a query the device gives back (a node with more than 15
+        children on its way, a queue beyond 256 entries) is evaluated by the host trees, as every tree-mode query was before."""
         pattern = list(pattern)[-self._max_depth:]
-        result = SuffixSpecResult()
-        if use_prompt:
-            h = N.lib().aic_sc_prompt_tree(self._h, self._key(req_id))
-            result = SuffixTree(self._max_depth, _handle=h, _owner=self).speculate(
+        if N.lib().aic_device_count() <= 0:       # the host trees alone (CPU tests of the tree code; as before r04)
+            return self._speculate_tree_mode_host(req_id, pattern, max_spec_tokens, factor, offset, min_prob, use_prompt)
+        a = _i32(pattern)
+        cap = max(1, int(max_spec_tokens))        # a tree candidate has branches: bounded by max_spec_tokens, not by max_depth
+        key = np.asarray([self._key(req_id)], np.int64)
+        lens = np.asarray([a.size], np.int32)
+        mst = np.asarray([max_spec_tokens], np.int32)
+        fac, off, mpr = (np.asarray([x], np.float32) for x in (factor, offset, min_prob))
+        upr = np.asarray([1 if use_prompt else 0], np.int32)
+        o_tok, o_par = np.zeros((1, cap), np.int32), np.zeros((1, cap), np.int32)
+        o_prb = np.zeros((1, cap), np.float32)
+        o_n, o_ml = np.zeros(1, np.int32), np.zeros(1, np.int32)
+        o_sc = np.zeros(1, np.float32)
+        N.check(N.lib().aic_sc_speculate_batch_tree(
+            self._h, 1, key.ctypes.data, a.ctypes.data, lens.ctypes.data, mst.ctypes.data, fac.ctypes.data, off.ctypes.data,
+            mpr.ctypes.data, upr.ctypes.data, cap, o_tok.ctypes.data, o_par.ctypes.data, o_prb.ctypes.data, o_n.ctypes.data,
+            o_sc.ctypes.data, o_ml.ctypes.data, _stream()))
+        k = int(o_n[0])
+        if k >= 0:
+            return SuffixSpecResult(o_tok[0, :k].tolist(), o_par[0, :k].tolist(), [float(x) for x in o_prb[0, :k]],
+                                    float(o_sc[0]), int(o_ml[0]))
+        return self._speculate_tree_mode_host(req_id, pattern, max_spec_tokens, factor, offset, min_prob, use_prompt)
+
+    def _speculate_tree_mode_host(self, req_id, pattern, max_spec_tokens, factor, offset, min_prob, use_prompt):
+        lib = N.lib()
+        lib.aic_debug_tree_mode_on_host(1)
+        try:
+            result = SuffixSpecResult()
+            if use_prompt:
+                h = lib.aic_sc_prompt_tree(self._h, self._key(req_id))
+                result = SuffixTree(self._max_depth, _handle=h, _owner=self).speculate(
+                    pattern, max_spec_tokens, factor, offset, min_prob, True)
+            g = SuffixTree(self._max_depth, _handle=lib.aic_sc_global_tree(self._h), _owner=self).speculate(
                 pattern, max_spec_tokens, factor, offset, min_prob, True)
-        g = SuffixTree(self._max_depth, _handle=N.lib().aic_sc_global_tree(self._h), _owner=self).speculate(
-            pattern, max_spec_tokens, factor, offset, min_prob, True)
-        return g if g.score > result.score else result
+            return g if g.score > result.score else result
+        finally:
+            lib.aic_debug_tree_mode_on_host(0)
 
     def speculate_batch(self, req_ids: Sequence[Hashable], patterns: Sequence[Sequence[int]],
                         max_spec_tokens: Sequence[int], max_spec_factor: Sequence[float],

@@ -77,9 +77,11 @@ int aic_st_num_seqs(const aic_suffix_tree* t);                 /* num_seqs   pyb
 int aic_st_append(aic_suffix_tree* t, int seq_id, int token);  /* append     pybind.cc:35 */
 int aic_st_extend(aic_suffix_tree* t, int seq_id, const int32_t* tokens /*host*/, int n); /* :36 */
 
-/* speculate (pybind.cc:37, suffix_tree.cc:135-165).  Path mode (use_tree_spec == 0) runs the HIP
- * matcher on `stream` and synchronises it before returning; tree mode (simulator-only in the
- * reference, never used in serving: model_runner.py:734-740) is evaluated by the host tree.
+/* speculate (pybind.cc:37, suffix_tree.cc:135-165).  Runs the HIP matcher on `stream` and synchronises it
+ * before returning: path mode (use_tree_spec == 0: _speculate_path) and, since r04, tree mode (_speculate_tree, the
+ * priority-queue expansion: simulator-only in the reference, never used in serving, model_runner.py:734-740) — see
+ * aic_sc_speculate_batch_tree; a tree-mode query the device gives back, and tree mode without a device, are evaluated by the
+ * host tree.
  * Outputs are host arrays of capacity `cap`; returns the number of tokens written (>= 0) or an
  * error (< 0). */
 int aic_st_speculate(aic_suffix_tree* t, const int32_t* pattern /*host*/, int n, int max_spec_tokens,
@@ -150,6 +152,23 @@ int aic_sc_speculate_batch(aic_suffix_cache* c, int n_query, const int64_t* reqs
                            const float* min_token_prob, const int32_t* use_prompt, int cap,
                            int32_t* out_tokens, float* out_probs, int32_t* out_n, float* out_score,
                            int32_t* out_match_len, void* stream);
+/* The same for tree-mode speculation (use_tree_spec = True: SuffixTree::_speculate_tree, suffix_tree.cc:226-274) ON THE DEVICE:
+ * one wavefront per (query, tree, suffix start) grows the candidate with a priority queue that reproduces libstdc++'s
+ * std::priority_queue (push_heap / pop_heap order among equal probabilities) over child lists mirrored in the host
+ * container's iteration order (switched on per tree by its first tree-mode query).  out_parents [n_query][cap].
+ * out_n[i] = -1: query i was given back (a node with more than 15 children, or a queue beyond 256 entries) — evaluate it on
+ * the host trees (aic_st_speculate with use_tree_spec on aic_sc_prompt_tree / aic_sc_global_tree after
+ * aic_debug_tree_mode_on_host(1)). */
+int aic_sc_speculate_batch_tree(aic_suffix_cache* c, int n_query, const int64_t* reqs, const int32_t* patterns,
+                                const int32_t* pattern_lens, const int32_t* max_spec_tokens,
+                                const float* max_spec_factor, const float* max_spec_offset,
+                                const float* min_token_prob, const int32_t* use_prompt, int cap,
+                                int32_t* out_tokens, int32_t* out_parents, float* out_probs, int32_t* out_n,
+                                float* out_score, int32_t* out_match_len, void* stream);
+/* tree-mode bookkeeping: queries answered by the device / given back to the host so far; _on_host(1) sends every tree-mode
+ * aic_st_speculate to the host trees (the A/B reference and the fallback's entry) */
+int aic_debug_tree_mode_stats(int64_t* on_device, int64_t* given_back);
+int aic_debug_tree_mode_on_host(int on);
 /* device time of the last aic_sc_speculate_batch matcher launch pair in microseconds (HIP events
  * on the caller's stream), and the number of bytes mirrored host->device for it */
 int aic_sc_last_stats(const aic_suffix_cache* c, float* match_us, int64_t* mirrored_bytes, int64_t* n_nodes_total);

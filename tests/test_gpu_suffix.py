@@ -223,3 +223,105 @@ def test_zero_copy_round_trip_gives_the_golden_digests():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, AIC_SUFFIX_ZEROCOPY="1"))
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# tree-mode speculation on the device (SuffixTree::_speculate_tree, suffix_tree.cc:226-274; r04)
+# ------------------------------------------------------------------------------------------------------------------
+def _tree_stats():
+    import ctypes
+    from arcticinference_amd import _native as N
+    a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+    N.check(N.lib().aic_debug_tree_mode_stats(ctypes.byref(a), ctypes.byref(b)))
+    return int(a.value), int(b.value)
+
+
+def test_tree_mode_goldens_are_answered_by_the_device():
+    """The reference-generated tree-mode vectors (suffix_treespec.json: use_tree_spec True on branching trees, min_token_prob
+    down to 0, budgets up to 32 tokens) replayed through the DEVICE path — kid lists mirrored in the host container's order,
+    one priority queue per wave reproducing std::priority_queue — bit for bit (tokens, PARENTS, f32 probabilities and
+    scores), with not one query handed back to the host trees."""
+    dev0, back0 = _tree_stats()
+    n_tree = 0
+    for case in gu.load("suffix_treespec.json"):
+        n_tree += sum(1 for ev in case["events"] if ev[0] == "spec" and ev[6])
+        gu.replay_tree_case(case, SuffixTree)
+    dev1, back1 = _tree_stats()
+    assert n_tree > 500 and dev1 - dev0 == n_tree and back1 == back0, (n_tree, dev1 - dev0, back1 - back0)
+
+
+@pytest.mark.parametrize("seed,vocab,depth", [(0, 5, 12), (1, 12, 16), (2, 40, 24), (3, 3, 64), (4, 200, 32)])
+def test_tree_mode_device_equals_host_trees(seed, vocab, depth):
+    """Fuzz: growing trees (several sequences, interleaved appends: every update case incl. re-keying and splits; vocabularies
+    from 3 to 200, so nodes range from 2 to MORE than 15 children — the latter are handed back to the host and must still
+    give the host's answer), tree-mode queries after every few appends, device against the host trees' own expansion
+    (aic_debug_tree_mode_on_host: suffix_host.hpp grow_tree, itself pinned by the goldens on CPU)."""
+    from arcticinference_amd import _native as N
+    rng = random.Random(100 + seed)
+    t = SuffixTree(depth)
+    hist = {s: [] for s in range(5)}
+    dev0, back0 = _tree_stats()
+    n_q = 0
+    for step in range(260):
+        s = rng.randrange(5)
+        # skewed token choice so that counts differ between siblings, with repeats so that deep matches exist
+        tok = min(int(rng.expovariate(0.6)), vocab - 1) if rng.random() < 0.8 else rng.randrange(vocab)
+        if hist[s] and rng.random() < 0.3:
+            k = rng.randrange(len(hist[s]))
+            tok = hist[s][k]
+        hist[s].append(tok)
+        t.append(s, tok)
+        if step % 3 != 2:
+            continue
+        src = hist[rng.randrange(5)]
+        if not src:
+            continue
+        e = rng.randint(1, len(src))
+        pat = src[max(0, e - rng.randint(1, depth)):e]
+        args = (rng.choice([1, 4, 8, 16, 32]), rng.choice([1.0, 2.0, 4.0]), rng.choice([0.0, 2.0]),
+                rng.choice([0.0, 0.02, 0.1, 0.25]), True)
+        got = t.speculate(pat, *args)
+        N.lib().aic_debug_tree_mode_on_host(1)
+        try:
+            want = t.speculate(pat, *args)
+        finally:
+            N.lib().aic_debug_tree_mode_on_host(0)
+        gu.assert_cand(got, gu.cand_dict(want), ctx=f"seed {seed} step {step}: pattern={pat} args={args}")
+        n_q += 1
+    dev1, back1 = _tree_stats()
+    assert (dev1 - dev0) + (back1 - back0) == n_q and dev1 > dev0
+    if vocab <= 12:
+        assert back1 == back0           # every node has at most 15 children: nothing may be handed back
+    if vocab >= 200:
+        assert back1 > back0            # the root-level nodes overflow the 15-entry lists: some queries were handed back
+    assert t.selfcheck() == 0
+
+
+def test_tree_mode_through_the_suffix_cache_on_the_device():
+    """SuffixCache.speculate(use_tree_spec=True): prompt tree and global tree in ONE device round trip, the prompt tree winning
+    ties, against the oracle's SuffixCache (the reference's policy over oracle trees) — and the simulator's call form."""
+    from oracle.suffix_oracle import OracleSuffixCache
+    rng = random.Random(11)
+    a, b = SuffixCache(12), OracleSuffixCache(12)
+    prompts = {r: [rng.randrange(6) for _ in range(40)] for r in range(3)}
+    for c in (a, b):
+        for r, p in prompts.items():
+            c.cache_prompt(r, p)
+    dev0, back0 = _tree_stats()
+    hist = {r: [] for r in prompts}
+    n = 0
+    for step in range(150):
+        r = rng.randrange(3)
+        tok = rng.randrange(6)
+        hist[r].append(tok)
+        for c in (a, b):
+            c.update_response(r, tok)
+        if step % 4 == 0:
+            pat = (prompts[r] + hist[r])[-rng.randint(1, 12):]
+            kw = dict(max_spec_tokens=rng.choice([4, 8, 16]), max_spec_factor=rng.choice([1.0, 2.0]),
+                      max_spec_offset=0.0, min_token_prob=rng.choice([0.0, 0.1]), use_tree_spec=True,
+                      use_cached_prompt=rng.random() < 0.7)
+            gu.assert_cand(a.speculate(r, pat, **kw), gu.cand_dict(b.speculate(r, pat, **kw)), ctx=f"step {step} {kw}")
+            n += 1
+    dev1, back1 = _tree_stats()
+    assert dev1 - dev0 == n and back1 == back0
