@@ -9,8 +9,9 @@ Rows of the dataset need a prompt and a response column (names configurable); bo
 (no tokenizer needed) or strings, in which case `--tokenizer` must name a tokenizer that is available locally.
 The model is the reference's (`simulator.py:33-114`): the target emits the recorded response; every step asks the
 cache for a candidate, accepts the longest root path that matches the recorded continuation, appends one bonus token
-and feeds the step's tokens back into the cache.  `use_tree_spec=true` candidates are evaluated on the host trees;
-`false` (what the vLLM plugin uses) runs the HIP matcher."""
+and feeds the step's tokens back into the cache.  Both candidate forms run the HIP matcher: `use_tree_spec=false` (what the
+vLLM plugin uses) and, since r04, `use_tree_spec=true` (the priority-queue expansion; a query that meets a node with more than
+15 children is evaluated on the host trees instead)."""
 from __future__ import annotations
 
 import argparse
