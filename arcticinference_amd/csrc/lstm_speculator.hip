@@ -29,6 +29,7 @@
 
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "aic_common.h"
@@ -1374,6 +1375,10 @@ int aic_lstm_create(const aic_lstm_config* cfg, const aic_lstm_weights* w, aic_l
   aic_lstm* m = new aic_lstm();
   m->cfg = *cfg;
   m->w = *w;
+  if (const char* e = std::getenv("AIC_LSTM_GATE_SPLITS")) {              // A/B switch: split-K of the gate projection (default 2)
+    const int v = std::atoi(e);
+    if (v >= 1 && v <= 8) m->gate_splits = v;
+  }
   const int Ds = cfg->inner_dim, H = cfg->input_hidden_dim, V = cfg->vocab_size;
   const double sw = std::pow(0.5, 0.5 / cfg->n_predict);                 // state_weight (:575)
   const double ew = std::sqrt((1.0 - sw * sw) * (static_cast<double>(Ds) / 2.0));  // emb_weight (:576-577)
