@@ -66,6 +66,7 @@ struct AttnParams {
   int num_q_heads;
   int num_kv_heads;
   int block_size;
+  int bs_shift;   // log2(block_size) when it is a power of two, else -1 (the long-draft body then divides)
   int n_splits;       // token-range splits of THIS launch
   int n_parts_total;  // partial slots per row the combine kernel reads (max over the launches of a call)
   int total_rows;  // T * Hq
@@ -208,6 +209,21 @@ __device__ __forceinline__ void swap16(float& a, float& b) {
 __device__ __forceinline__ void swap32(float& a, float& b) {
   asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b));
 }
+// maxima without the canonicalising v_max(x, x) the compiler puts in front of every fmaxf of a value it cannot prove quiet
+// (MFMA results): scores are never signalling NaNs
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float max_nc(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr float kLazySlack = 6.0f;   // long-draft body: a row's adopted maximum may trail the true one by this much (base-2 exponent)
+
 __device__ __forceinline__ float rowgroup_max(float x) {
   float a = x, b = x;
   swap16(a, b);
@@ -759,18 +775,33 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((M
 // the PV MFMAs.  Straight-line code: with one soft-max call per row tile the calls' branches kept the MFMA
 // chains and the VALU work of different row tiles from overlapping, and the wave (alone on its SIMD) ran at the
 // sum of every latency.
-template <int NT, int RT, int D>
-__device__ __forceinline__ void long_tile_compute(const char* kb, const char* vb, const uint4 (&qf)[RT][D / 32],
+template <int NT, int RT, int D, bool TR, int NP, typename Dma>
+__device__ __forceinline__ void long_tile_compute(const unsigned (&ka)[D / 32], const unsigned (&va)[D / 16], unsigned slot_off,
+                                                  const uint4 (&qf)[RT][D / 32],
                                                   const bool (&row_ok)[RT], const int (&row_pos)[RT],
-                                                  float (&m_run)[RT], float (&l_run)[RT], f32x4 (&o_acc)[RT][D / 16], int tt,
-                                                  int t_end, int ctx, int q_len, int wnd, float scale_log2, int g, int c16) {
-    // K fragments of the tile (A operand of S^T = K Q^T): lane (token c16 [+16], d = 32 s + 8 g)
+                                                  float (&m_run)[RT], float (&m_use)[RT], float (&thr)[RT], f32x2 (&l_run)[RT],
+                                                  f32x4 (&o_acc)[RT][D / 16], int tt, int t_end, int ctx, int q_len, int wnd,
+                                                  float scale_log2, float inv_scale, int g, int c16, const Dma& dma,
+                                                  uint64_t* cyc = nullptr) {
+    // ka / va: this lane's LDS byte addresses of its K fragments (k-step s, tokens c16 and, 16 rows on, 16 + c16) and of its
+    // transposed V reads (output tile dt) in ring slot 0; slot_off: the tile's slot — one add per address and tile.
+    // dma(i), i < NP: the next tile's LDS-DMA pieces of this wave, issued one by one between the row tiles' soft-max blocks
+    // (VALU-only stretches) instead of back to back at the loop head
+    // TR (aic_debug_attn_phase_trace on a long-only call): shader-clock cycles of this wave per phase, summed over its tiles —
+    // cyc[1] K fragments read + score MFMAs issued, cyc[2] soft-max (waits for the scores), cyc[3] V reads + PV MFMAs issued
+    uint64_t c0 = 0;
+    if constexpr (TR) c0 = __builtin_amdgcn_s_memtime();
     constexpr int DS = D / 32, DT = D / 16;   // k-steps of the score MFMAs, 16-wide output tiles
-    uint4 kf[2][DS];
+    constexpr unsigned kHalf = 16 * D * 2;    // 16 token rows further on in an image
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef const u32x4 __attribute__((address_space(3))) * lds_u4;
+    u32x4 kf[2][DS];
 #pragma unroll
-    for (int th = 0; th < 2; ++th)
-#pragma unroll
-      for (int s = 0; s < DS; ++s) kf[th][s] = *reinterpret_cast<const uint4*>(kb + tile_off<D>(16 * th + c16, 4 * s + g));
+    for (int s = 0; s < DS; ++s) {
+      const unsigned a = ka[s] + slot_off;
+      kf[0][s] = *reinterpret_cast<lds_u4>(a);
+      kf[1][s] = *reinterpret_cast<lds_u4>(a + kHalf);
+    }
 
     f32x4 st[NT][2];
 #pragma unroll
@@ -785,6 +816,11 @@ __device__ __forceinline__ void long_tile_compute(const char* kb, const char* vb
         for (int th = 0; th < 2; ++th)
           st[mt][th] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[th][s]),
                                                                __builtin_bit_cast(bf16x8, qf[mt][s]), st[mt][th], 0, 0, 0);
+    if constexpr (TR) {
+      const uint64_t c1 = __builtin_amdgcn_s_memtime();
+      cyc[1] += c1 - c0;
+      c0 = c1;
+    }
     const bool need_mask = tt + kTile > t_end || tt + kTile > ctx - q_len + 1 || tt < ctx - wnd;
     if (need_mask) {
 #pragma unroll
@@ -799,17 +835,37 @@ __device__ __forceinline__ void long_tile_compute(const char* kb, const char* vb
           }
       }
     }
-    float alpha[NT], m_use[NT];
+    // The soft-max of this body is VALU-bound (tools/microbench.py longphases: of 4485 cycles per KV tile on the wave with
+    // three row tiles, 1937 were this block, 1311 the 72 MFMAs), so the row maximum is LAZY: a row keeps the maximum m it
+    // last adopted while no score of the tile exceeds it by more than kLazySlack (in the exponent's base-2 units: weights
+    // stay below 2^kLazySlack, far inside f32 and bf16 range; the hi/lo split of P keeps relative precision at any
+    // magnitude).  The common tile then costs one max3 chain and one compare per row tile — no cross-lane exchange, no
+    // alpha, no rescale; when some lane of the wave sees a larger score, every row tile of the wave takes the exact path.
+    float lmax[NT];
+    bool over = false;
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
       const f32x4 &a = st[mt][0], &b = st[mt][1];
-      const float tmax = rowgroup_max(fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])),
-                                            fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]))));
-      const float m_new = fmaxf(m_run[mt], tmax * scale_log2);
-      // a row with nothing visible yet keeps m = -inf; exponents are then taken against 0 (all scores are -inf)
-      m_use[mt] = m_new == -INFINITY ? 0.0f : m_new;
-      alpha[mt] = __builtin_amdgcn_exp2f(m_run[mt] - m_use[mt]);
-      m_run[mt] = m_new;
+      lmax[mt] = max3f(max3f(max3f(a[0], a[1], a[2]), a[3], b[0]), b[1], max_nc(b[2], b[3]));
+      over = over || lmax[mt] > thr[mt];
+    }
+    if (__any(over)) {
+      float alpha[NT];
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt) {
+        const float tmax = rowgroup_max(lmax[mt]);
+        const float m_new = fmaxf(m_run[mt], tmax * scale_log2);
+        // a row with nothing visible yet keeps m = -inf; exponents are then taken against 0 (all scores are -inf)
+        m_use[mt] = m_new == -INFINITY ? 0.0f : m_new;
+        alpha[mt] = __builtin_amdgcn_exp2f(m_run[mt] - m_use[mt]);
+        m_run[mt] = m_new;
+        thr[mt] = __builtin_fmaf(m_new, inv_scale, kLazySlack * inv_scale);
+        l_run[mt] *= alpha[mt];
+      }
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o_acc[mt][dt] *= alpha[mt];
     }
     // (P as ONE bf16 operand with the row sum taken over the rounded weights — what kernels that feed P to the matrix unit
     // in the value dtype do — was measured: long-only B=16 x 33 134 -> 103 us together with two workgroups per CU, but a
@@ -817,37 +873,54 @@ __device__ __forceinline__ void long_tile_compute(const char* kb, const char* vb
     bf16x8 pfrag[NT], pfrag_lo[NT];
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
-      float pv[8], psum = 0.0f;
+      // pieces i with i * (NT + 1) / NP == mt go out before this row tile's block, the rest after the last one.  Nothing
+      // orders a volatile asm against arithmetic, so each piece is tied into the data flow: it consumes the results of the block
+      // before it and the block after it reads its first score through it.
+      if constexpr (NP > 0) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+          if (i * (NT + 1) / NP == mt) {
+            if (mt == 0) asm volatile("" : "+v"(st[0][0][0]) : "v"(lmax[0]));
+            else asm volatile("" : "+v"(st[mt][0][0]) : "v"(pfrag[mt > 0 ? mt - 1 : 0]), "v"(pfrag_lo[mt > 0 ? mt - 1 : 0]));
+            dma(i);
+            asm volatile("" : "+v"(st[mt][0][0]));
+          }
+      }
+      // (scalar f32 arithmetic on purpose: packed f32 VALU beside MFMAs costs more issue time than the two scalar
+      // instructions it replaces — MI355X_MICROARCH.md, cycle constants)
+      float pv[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[mt][e >> 2][e & 3], scale_log2, -m_use[mt]));
-        psum += pv[e];
+        l_run[mt][e & 1] += pv[e];
       }
-      l_run[mt] = l_run[mt] * alpha[mt] + psum;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         pfrag[mt][e] = static_cast<__bf16>(pv[e]);
         pfrag_lo[mt][e] = static_cast<__bf16>(pv[e] - static_cast<float>(pfrag[mt][e]));
       }
     }
-    bool steady = true;  // no row maximum moved in this tile (the common case after the first few tiles)
+    if constexpr (NP > 0 && NT > 0) {
 #pragma unroll
-    for (int mt = 0; mt < NT; ++mt) steady = steady && alpha[mt] == 1.0f;
-    if (!__all(steady)) {
-#pragma unroll
-      for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) o_acc[mt][dt] *= alpha[mt];
+      for (int i = 0; i < NP; ++i)
+        if (i * (NT + 1) / NP >= NT) {
+          asm volatile("" : "+v"(pfrag[0]) : "v"(pfrag_lo[NT - 1]));
+          dma(i);
+          asm volatile("" : "+v"(pfrag[0]));
+        }
     }
-    const int q4 = c16 >> 2, p4 = c16 & 3;
+    if constexpr (TR) {
+      asm volatile("" :: "v"(pfrag[0]), "v"(pfrag_lo[NT - 1]));
+      const uint64_t c2 = __builtin_amdgcn_s_memtime();
+      cyc[2] += c2 - c0;
+      c0 = c2;
+    }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
-      const char* a_lo = vb + tile_off<D>(4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
-      const char* a_hi = vb + tile_off<D>(16 + 4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(a_lo)));
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (s16x4 __attribute__((address_space(3)))*)(const_cast<char*>(a_hi)));
+      typedef s16x4 __attribute__((address_space(3))) * lds_tr;
+      const unsigned a = va[dt] + slot_off;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_tr>(a));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_tr>(a + kHalf));
       typedef __attribute__((ext_vector_type(8))) short s16x8;
       const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       const bf16x8 vfrag = __builtin_bit_cast(bf16x8, both);
@@ -857,6 +930,7 @@ __device__ __forceinline__ void long_tile_compute(const char* kb, const char* vb
         o_acc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pfrag_lo[mt], o_acc[mt][dt], 0, 0, 0);
       }
     }
+    if constexpr (TR) cyc[3] += __builtin_amdgcn_s_memtime() - c0;
 }
 
 constexpr int kLongTilesPerWave = 3;
@@ -890,6 +964,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                : "memory");
 }
 
+// the same with a wave-uniform base (SGPR pair) and a 32-bit per-lane byte offset: no 64-bit per-lane address arithmetic
+__device__ __forceinline__ void glds16s(const char* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+
 constexpr int kLong4LdsU4 = kLongRing * 2 * kTile * 16;
 
 // Body of the co-resident long-draft kernel for workgroup (bx, by, bz); lds = kLong4LdsU4 uint4 of LDS.
@@ -899,9 +982,15 @@ constexpr int kLong4LdsU4 = kLongRing * 2 * kTile * 16;
 // tile.  k_scale folds into the soft-max scale, v_scale into the output.
 // D = 64 (bf16 cache only): 128-byte rows, i.e. the DMA geometry of the fp8 case without the conversion (long drafts of a
 // head-size-64 model; requests of up to 32 rows take the streaming body's HD = 64 form).
-template <bool KV8, int D>
+template <bool KV8, int D, bool TR = false>
 __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint4* lds, const int bx, const int by, const int bz) {
   static_assert(D == 128 || (D == 64 && !KV8), "head size 128, or 64 with a bf16 cache");
+  uint64_t cyc[6] = {0, 0, 0, 0, 0, 0};   // TR: [0] issuing the next tile's DMA, [1..3] long_tile_compute, [4] vmcnt wait, [5] barrier
+  uint64_t c_entry = 0, rt_entry = 0;
+  if constexpr (TR) {
+    c_entry = __builtin_amdgcn_s_memtime();
+    rt_entry = __builtin_amdgcn_s_memrealtime();
+  }
   constexpr int RT = kLongTilesPerWave;
   constexpr int DS = D / 32, DT = D / 16;
   constexpr bool ROW128 = KV8 || D == 64;          // a token row of the DMA source is 128 bytes (else 256)
@@ -965,16 +1054,24 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
     for (int s = 0; s < DS; ++s)
       asm volatile("" : "+v"(qf[mt][s].x), "+v"(qf[mt][s].y), "+v"(qf[mt][s].z), "+v"(qf[mt][s].w));
 
-  float m_run[RT], l_run[RT];
+  // per row tile: m_run the maximum the row last adopted (scaled; -inf = nothing visible yet), m_use the value exponents are
+  // taken against, thr the raw score above which the row must adopt a new maximum (long_tile_compute), l_run this lane's
+  // share of the row's sum (two partial sums)
+  const float inv_scale = 1.0f / scale_log2;
+  float m_run[RT], m_use[RT], thr[RT];
+  f32x2 l_run[RT];
   f32x4 o_acc[RT][DT];
 #pragma unroll
   for (int mt = 0; mt < RT; ++mt) {
     m_run[mt] = -INFINITY;
-    l_run[mt] = 0.0f;
+    m_use[mt] = 0.0f;
+    thr[mt] = -INFINITY;
+    l_run[mt] = f32x2{0.0f, 0.0f};
     if (P.sinks != nullptr && by == 0) {        // first partial of the row: starts from the sink
       const int rc = min(row_base + (wave + 4 * mt) * 16 + c16, n_rows - 1);
-      m_run[mt] = P.sinks[h * G + (rc - (rc / G) * G)] * kLog2e;
-      l_run[mt] = g == 0 ? 1.0f : 0.0f;         // (here l_run is a per-lane share of the row's sum: one lane carries the 1)
+      m_run[mt] = m_use[mt] = P.sinks[h * G + (rc - (rc / G) * G)] * kLog2e;
+      thr[mt] = __builtin_fmaf(m_run[mt], inv_scale, kLazySlack * inv_scale);
+      l_run[mt][0] = g == 0 ? 1.0f : 0.0f;      // (a per-lane share of the row's sum: one lane carries the 1)
     }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) o_acc[mt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -993,29 +1090,115 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
   const int r0 = 4 * wave + g;                                             // < 16: first page of the tile
   const int tk = ROW128 ? 8 * wave + (lane >> 3) : (r0 & ~12) | ((r0 & 4) << 1) | ((r0 & 8) >> 1);
   const int ch = KV8 ? (lane & 7) : D == 64 ? ((lane & 7) ^ (tk & 7)) : c16 ^ (((r0 & 3) << 2) | ((r0 >> 2) & 3));
-  auto issue = [&](int jt) {
-    const int tt = t_begin + jt * kTile;
-    if constexpr (ROW128) {
-      constexpr int EB = KV8 ? 1 : 2;   // bytes per cache element
-      const int half = wave >> 1;       // tokens 0-15 / 16-31 of the tile: one page lookup per wave
-      const int f = min(tt + 16 * half, last_group);
-      const int64_t b = static_cast<int64_t>(btab[f / bs]) * P.block_stride + static_cast<int64_t>(f % bs) * kv_row + h * D;
-      const int64_t o = EB * (b + static_cast<int64_t>(min(tt + tk, ctx - 1) - f) * kv_row) + 16 * ch;
-      const unsigned slot = lds0 + static_cast<unsigned>(jt & (kLongRing - 1)) * kRawSlot + 1024 * wave;
-      glds16(kc + o, slot);
-      glds16(vc + o, slot + kRawSlot / 2);
+  // (Everything per tile below is scalar, unsigned and 32-bit where it can be: one wave issues about one instruction every
+  // four cycles whatever its kind, and the first count of this loop had 215 scalar instructions per tile beside 152 vector
+  // ones — four emulated signed divisions and six 64-bit multiplies among them.)
+  const int bsh = P.bs_shift;
+  auto page_of = [&](unsigned f, unsigned& pg, unsigned& po) {
+    if (bsh >= 0) {
+      pg = f >> bsh;
+      po = f & static_cast<unsigned>(bs - 1);
     } else {
-      const int f0 = min(tt, last_group), f1 = min(tt + 16, last_group);
-      const int64_t b0 = static_cast<int64_t>(btab[f0 / bs]) * P.block_stride + static_cast<int64_t>(f0 % bs) * kv_row + h * D;
-      const int64_t b1 = static_cast<int64_t>(btab[f1 / bs]) * P.block_stride + static_cast<int64_t>(f1 % bs) * kv_row + h * D;
-      const int64_t o0 = 2 * (b0 + static_cast<int64_t>(min(tt + tk, ctx - 1) - f0) * kv_row + 8 * ch);
-      const int64_t o1 = 2 * (b1 + static_cast<int64_t>(min(tt + 16 + tk, ctx - 1) - f1) * kv_row + 8 * ch);
-      const unsigned slot = lds0 + static_cast<unsigned>(jt & (kLongRing - 1)) * (2 * kImg) + 1024 * wave;
-      glds16(kc + o0, slot);
-      glds16(kc + o1, slot + 4096);
-      glds16(vc + o0, slot + kImg);
-      glds16(vc + o1, slot + kImg + 4096);
+      pg = f / static_cast<unsigned>(bs);
+      po = f - pg * static_cast<unsigned>(bs);
     }
+  };
+  // The block-table entries of this workgroup's token range live in ONE register, lane i holding page pg_base + i (one
+  // coalesced load covers 64 pages = 1024 tokens at 16-token pages); a tile takes its two with v_readlane.  Scalar loads
+  // looked cheaper and were not: they share lgkmcnt with the LDS reads and return out of order, so the first fragment wait
+  // of every tile (lgkmcnt(0)) also waited out their round trip — ~600 cycles per tile on every wave (longphases).  A range
+  // longer than 64 pages refills the register (a plain load the compiler waits for: once per 32 tiles).
+  unsigned pg_base, po_unused;
+  page_of(static_cast<unsigned>(min(t_begin, last_group)), pg_base, po_unused);
+  int vpages = btab[min(static_cast<int>(pg_base) + lane, P.max_blocks - 1)];
+  // (`steady`: tile jt is not the last of its range — all 32 tokens exist, nothing to clamp)
+  auto pages = [&](int jt, int& pa, int& pb, auto steady) {
+    const int tt = t_begin + jt * kTile;
+    unsigned pg0, pg1, po;
+    if constexpr (ROW128) {
+      page_of(static_cast<unsigned>(min(tt + 16 * (wave >> 1), last_group)), pg0, po);
+      pg1 = pg0;
+    } else if constexpr (decltype(steady)::value) {
+      page_of(static_cast<unsigned>(tt), pg0, po);
+      page_of(static_cast<unsigned>(tt + 16), pg1, po);
+    } else {
+      page_of(static_cast<unsigned>(min(tt, last_group)), pg0, po);
+      page_of(static_cast<unsigned>(min(tt + 16, last_group)), pg1, po);
+    }
+    if (pg1 - pg_base >= 64u) {
+      pg_base = pg0;
+      vpages = btab[min(static_cast<int>(pg_base) + lane, P.max_blocks - 1)];
+      asm volatile("" : "+v"(vpages));   // the compiler's wait for this load stays inside the branch
+    }
+    pa = __builtin_amdgcn_readlane(vpages, static_cast<int>(pg0 - pg_base));
+    pb = __builtin_amdgcn_readlane(vpages, static_cast<int>(pg1 - pg_base));
+  };
+  // A tile's DMA = kPieces LDS-DMA instructions per wave (1 KiB each).  Their source addresses are a wave-uniform base per
+  // 16-token group (page, row within the page, kv head: scalar arithmetic) plus a per-lane byte offset that is the same for
+  // every tile whose 32 tokens all exist (`loff`); only the context's last tile clamps rows per lane.  (The cycle accounting
+  // had 770-870 cycles per tile and wave in this block when it computed 64-bit per-lane addresses and issued the four
+  // instructions back to back: an LDS-DMA instruction among busy phases costs 100-185 cycles to issue, 25-60 in a VALU-only
+  // stretch — MI355X_MICROARCH.md, cycle constants — so the pieces are handed to long_tile_compute one by one.)
+  constexpr int kPieces = ROW128 ? 2 : 4;
+  constexpr int EB = KV8 ? 1 : 2;   // bytes per cache element
+  const unsigned row_bytes = static_cast<unsigned>(kv_row) * EB;
+  const unsigned loff = ROW128 ? static_cast<unsigned>(tk - 16 * (wave >> 1)) * row_bytes + 16u * ch
+                               : static_cast<unsigned>(tk) * row_bytes + 16u * ch;
+  struct TileDma {
+    const char *k0, *k1, *v0, *v1;
+    unsigned l0, l1, slot;
+    bool on;
+  } td;
+  td.on = false;
+  const uint64_t stride_bytes = static_cast<uint64_t>(P.block_stride) * EB;
+  const unsigned head_off = static_cast<unsigned>(h * D);
+  // byte offset of (page, first token f of a 16-token group) for this kv head
+  auto group_base = [&](int page, unsigned f) -> uint64_t {
+    unsigned pg, po;
+    page_of(f, pg, po);
+    return static_cast<uint64_t>(static_cast<unsigned>(page)) * stride_bytes + (po * static_cast<unsigned>(kv_row) + head_off) * EB;
+  };
+  auto prep = [&](int jt, int pa, int pb, auto steady) {
+    constexpr bool kSteady = decltype(steady)::value;
+    const int tt = t_begin + jt * kTile;
+    td.on = true;
+    const bool full = kSteady || tt + kTile <= ctx;
+    if constexpr (ROW128) {
+      const int f = min(tt + 16 * (wave >> 1), last_group);   // tokens 0-15 / 16-31 of the tile: one page per wave
+      const uint64_t b = group_base(pa, static_cast<unsigned>(f));
+      td.k0 = kc + b;
+      td.v0 = vc + b;
+      td.l0 = full ? loff : static_cast<unsigned>(min(tt + tk, ctx - 1) - f) * row_bytes + 16u * ch;
+      td.slot = lds0 + static_cast<unsigned>(jt & (kLongRing - 1)) * kRawSlot + 1024 * wave;
+    } else {
+      const int f0 = kSteady ? tt : min(tt, last_group), f1 = kSteady ? tt + 16 : min(tt + 16, last_group);
+      const uint64_t b0 = group_base(pa, static_cast<unsigned>(f0)), b1 = group_base(pb, static_cast<unsigned>(f1));
+      td.k0 = kc + b0;
+      td.k1 = kc + b1;
+      td.v0 = vc + b0;
+      td.v1 = vc + b1;
+      td.l0 = full ? loff : static_cast<unsigned>(min(tt + tk, ctx - 1) - f0) * row_bytes + 16u * ch;
+      td.l1 = full ? loff : static_cast<unsigned>(min(tt + 16 + tk, ctx - 1) - f1) * row_bytes + 16u * ch;
+      td.slot = lds0 + static_cast<unsigned>(jt & (kLongRing - 1)) * (2 * kImg) + 1024 * wave;
+    }
+  };
+  auto piece = [&](int i) {          // i is a compile-time constant at every call site
+    if (!td.on) return;
+    if constexpr (ROW128) {
+      if (i == 0) glds16s(td.k0, td.l0, td.slot);
+      else if (i == 1) glds16s(td.v0, td.l0, td.slot + kRawSlot / 2);
+    } else {
+      if (i == 0) glds16s(td.k0, td.l0, td.slot);
+      else if (i == 1) glds16s(td.k1, td.l1, td.slot + 4096);
+      else if (i == 2) glds16s(td.v0, td.l0, td.slot + kImg);
+      else if (i == 3) glds16s(td.v1, td.l1, td.slot + kImg + 4096);
+    }
+  };
+  auto issue = [&](int jt, int pa, int pb) {
+    prep(jt, pa, pb, std::false_type{});
+#pragma unroll
+    for (int i = 0; i < kPieces; ++i) piece(i);
+    td.on = false;
   };
   // fp8: this wave's quarter of raw tile jt -> bf16 image jt & 1
   auto convert = [&](int jt) {
@@ -1046,9 +1229,14 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
     }
   };
   constexpr int kAhead = KV8 ? kLongRing : kLongAhead;   // tiles issued before the loop
+  asm volatile("" : "+v"(vpages));   // (a compiler-counted load, like Q: retired before the first DMA is in flight)
 #pragma unroll
   for (int d = 0; d < kAhead; ++d)
-    if (d < n_iter) issue(d);
+    if (d < n_iter) {
+      int pa, pb;
+      pages(d, pa, pb, std::false_type{});
+      issue(d, pa, pb);
+    }
   if (KV8 && n_iter > 0) {
     wait_tiles(min(n_iter, kAhead) - 1);
     __builtin_amdgcn_s_barrier();   // tile 0 is in the ring
@@ -1056,30 +1244,81 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
     convert(0);
   }
 
-  auto tile_loop = [&](auto nt_tag) {
+  // LDS addresses of this lane's fragment reads in image slot 0 (long_tile_compute adds the tile's slot)
+  unsigned ka[DS], va[DT];
+  {
+    const unsigned img0 = lds0 + kImgBase;
+#pragma unroll
+    for (int s = 0; s < DS; ++s) ka[s] = img0 + tile_off<D>(c16, 4 * s + g);
+    const int q4 = c16 >> 2, p4 = c16 & 3;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) va[dt] = img0 + kImg + tile_off<D>(4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
+  }
+  uint64_t c_loop = 0;
+  if constexpr (TR) c_loop = __builtin_amdgcn_s_memtime();
+  // One iteration = one KV tile.  `steady` iterations (bf16 cache: those whose issued tile it + 3 is not the last of the range)
+  // run with constant waits and unclamped addresses; the last four take the general form.
+  auto tile_iter = [&](int it, auto nt_tag, auto steady) {
     constexpr int NT = decltype(nt_tag)::value;
-    for (int it = 0; it < n_iter; ++it) {
-      if constexpr (KV8) {
-        // tile it + 1 must have landed (it is converted below); tiles it + 2, it + 3 may still be in flight
-        wait_tiles(min(2, max(0, n_iter - it - 2)));
-        __builtin_amdgcn_s_barrier();  // bf16 image of tile `it` complete; raw slot it & 3 and image (it + 1) & 1 are free
-        asm volatile("" ::: "memory");
-        if (it + kLongRing < n_iter) issue(it + kLongRing);
-        if (it + 1 < n_iter) convert(it + 1);
-      } else {
-        // tile `it` has landed when at most the tiles issued after it are still outstanding
-        wait_tiles(min(2, n_iter - 1 - it));
-        __builtin_amdgcn_s_barrier();  // every wave's quarter of tile `it` is in LDS; ring slot (it - 1) & 3 is free
-        asm volatile("" ::: "memory");
-        if (it + kLongAhead < n_iter) issue(it + kLongAhead);
+    constexpr bool kSteady = decltype(steady)::value;
+    uint64_t c_top = 0;
+    if constexpr (TR) c_top = __builtin_amdgcn_s_memtime();
+    if constexpr (KV8) {
+      // tile it + 1 must have landed (it is converted below); tiles it + 2, it + 3 may still be in flight
+      wait_tiles(min(2, max(0, n_iter - it - 2)));
+      __builtin_amdgcn_s_barrier();  // bf16 image of tile `it` complete; raw slot it & 3 and image (it + 1) & 1 are free
+      asm volatile("" ::: "memory");
+      if (it + kLongRing < n_iter) {
+        int pa, pb;
+        pages(it + kLongRing, pa, pb, std::false_type{});
+        issue(it + kLongRing, pa, pb);
       }
-      if constexpr (NT > 0) {
-        const int slot = KV8 ? (it & 1) : (it & (kLongRing - 1));
-        const char* kb = lds_b + kImgBase + slot * (2 * kImg);
-        long_tile_compute<NT, RT, D>(kb, kb + kImg, qf, row_ok, row_pos, m_run, l_run, o_acc, t_begin + it * kTile, t_end,
-                                     ctx, q_len, wnd, scale_log2, g, c16);
+      if (it + 1 < n_iter) convert(it + 1);
+    } else {
+      // tile `it` has landed when at most the tiles issued after it are still outstanding
+      if constexpr (kSteady) wait_tiles(2);
+      else wait_tiles(min(2, n_iter - 1 - it));
+      if constexpr (TR) {
+        const uint64_t c = __builtin_amdgcn_s_memtime();
+        cyc[4] += c - c_top;
+        c_top = c;
+      }
+      __builtin_amdgcn_s_barrier();  // every wave's quarter of tile `it` is in LDS; ring slot (it - 1) & 3 is free
+      asm volatile("" ::: "memory");
+      if constexpr (TR) {
+        const uint64_t c = __builtin_amdgcn_s_memtime();
+        cyc[5] += c - c_top;
+        c_top = c;
+      }
+      td.on = false;
+      if (kSteady || it + kLongAhead < n_iter) {
+        int pa, pb;
+        pages(it + kLongAhead, pa, pb, steady);
+        prep(it + kLongAhead, pa, pb, steady);
+      }
+      if constexpr (NT == 0) {      // a wave without rows: nothing to spread the pieces over
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) piece(i);
       }
     }
+    if constexpr (TR) cyc[0] += __builtin_amdgcn_s_memtime() - c_top;
+    if constexpr (NT > 0) {
+      const unsigned slot_off = static_cast<unsigned>(KV8 ? (it & 1) : (it & (kLongRing - 1))) * (2 * kImg);
+      auto dma = [&](int i) {
+        if constexpr (!KV8) piece(i);   // (fp8: the tile's DMA went out at the loop head, before the conversion)
+      };
+      long_tile_compute<NT, RT, D, TR, KV8 ? 0 : kPieces>(ka, va, slot_off, qf, row_ok, row_pos, m_run, m_use, thr, l_run, o_acc,
+                                                           t_begin + it * kTile, t_end, ctx, q_len, wnd, scale_log2, inv_scale,
+                                                           g, c16, dma, cyc);
+    }
+  };
+  auto tile_loop = [&](auto nt_tag) {
+    int it = 0;
+    if constexpr (!KV8) {
+      const int n_steady = n_iter - 1 - kLongAhead;   // issued tile it + 3 <= n_iter - 2
+      for (; it < n_steady; ++it) tile_iter(it, nt_tag, std::true_type{});
+    }
+    for (; it < n_iter; ++it) tile_iter(it, nt_tag, std::false_type{});
   };
   if (my_tiles >= 3) {
     tile_loop(std::integral_constant<int, 3>{});
@@ -1091,9 +1330,31 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
     tile_loop(std::integral_constant<int, 0>{});  // no rows of its own: the wave still moves its quarter of the tiles
   }
 
+  if constexpr (TR) {
+    if (P.ptrace && lane == 0) {
+      const uint64_t c_end = __builtin_amdgcn_s_memtime();
+      int64_t* r = P.ptrace + (((static_cast<int64_t>(bz) * gridDim.y + by) * gridDim.x + bx) * 4 + wave) * 16;
+      r[0] = static_cast<int64_t>(c_loop - c_entry);   // prologue: geometry, Q rows, first tiles issued
+      r[1] = static_cast<int64_t>(c_end - c_loop);     // the tile loop
+      r[2] = static_cast<int64_t>(cyc[0]);
+      r[3] = static_cast<int64_t>(cyc[1]);
+      r[4] = static_cast<int64_t>(cyc[2]);
+      r[5] = static_cast<int64_t>(cyc[3]);
+      r[6] = (static_cast<int64_t>(n_iter) << 8) | my_tiles;
+      r[7] = static_cast<int64_t>(__builtin_amdgcn_s_memrealtime());
+      r[8] = static_cast<int64_t>(cyc[4]);
+      r[9] = static_cast<int64_t>(cyc[5]);
+      r[10] = static_cast<int64_t>(rt_entry);
+      r[11] = static_cast<int64_t>(c_end - c_entry);
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      r[12] = static_cast<int64_t>(hw) | (static_cast<int64_t>(xcc) << 32);
+    }
+  }
   float l_tot[RT];
 #pragma unroll
-  for (int mt = 0; mt < RT; ++mt) l_tot[mt] = rowgroup_sum(l_run[mt]);
+  for (int mt = 0; mt < RT; ++mt) l_tot[mt] = rowgroup_sum(l_run[mt][0] + l_run[mt][1]);
 #pragma unroll
   for (int mt = 0; mt < RT; ++mt) {
     if (!row_ok[mt]) continue;
@@ -1115,10 +1376,10 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
   }
 }
 
-template <bool KV8, int D = 128>
+template <bool KV8, int D = 128, bool TR = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) verify_attn_long4_kernel(AttnParams P) {
   __shared__ uint4 lds[kLong4LdsU4];
-  verify_attn_long4_body<KV8, D>(P, lds, blockIdx.x, blockIdx.y, blockIdx.z);
+  verify_attn_long4_body<KV8, D, TR>(P, lds, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Short requests and long drafts of one call in ONE launch: workgroups [0, n_long_wg) run the long-draft body,
@@ -1580,6 +1841,7 @@ int aic_verify_attention_win(const void* q, int64_t q_stride, const void* k_cach
   P.num_q_heads = num_q_heads;
   P.num_kv_heads = num_kv_heads;
   P.block_size = block_size;
+  P.bs_shift = (block_size & (block_size - 1)) == 0 ? __builtin_ctz(static_cast<unsigned>(block_size)) : -1;
   P.n_splits = n_splits;
   P.n_parts_total = n_parts_total;
   P.total_rows = static_cast<int>(rows);
@@ -1717,7 +1979,10 @@ int aic_verify_attention_win(const void* q, int64_t q_stride, const void* k_cach
       const int per_block_rows = 4 * kLongTilesPerWave * 16;
       PL.n_splits = n_splits_long;
       dim3 grid(static_cast<unsigned>(n_long * num_kv_heads), n_splits_long, (max_rows + per_block_rows - 1) / per_block_rows);
-      if (d64)
+      if (g_attn_ptrace && !d64 && !kv8 && n_short == 0 && static_cast<int>(grid.x * grid.y * grid.z) * 8 <= g_attn_ptrace_cap) {
+        PL.ptrace = g_attn_ptrace;   // debug: per-wave cycle accounting of a long-only call (tools/microbench.py longphases)
+        launch(verify_attn_long4_kernel<false, 128, true>, grid, dim3(256), s, PL);
+      } else if (d64)
         launch(verify_attn_long4_kernel<false, 64>, grid, dim3(256), overlap ? side->stream : s, PL);
       else if (kv8)
         launch(verify_attn_long4_kernel<true, 128>, grid, dim3(256), overlap ? side->stream : s, PL);

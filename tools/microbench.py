@@ -227,6 +227,43 @@ def attn_phases(n_short=32, ctx=4224, kv8=False, Hq=32, Hkv=8, D=128, bs=16):
           f"last end - median end {us(t[:, 5].max() - np.median(t[:, 5])):.1f} us")
 
 
+def attn_long_phases(B=16, q_long=33, ctx=4096, Hq=32, Hkv=8, D=128, bs=16):
+    """Shader-clock cycle accounting of the long-draft body per wave (aic_debug_attn_phase_trace on a long-only call)."""
+    nblk = (ctx + bs - 1) // bs
+    nb = B * nblk
+    kv = torch.randn(2, nb, bs, Hkv, D, device=dev, dtype=torch.bfloat16)
+    bt = torch.randperm(nb, device=dev).to(torch.int32).view(B, nblk)
+    ql = [q_long] * B
+    q = torch.randn(sum(ql), Hq, D, device=dev, dtype=torch.bfloat16)
+    seq = torch.full((B,), ctx, dtype=torch.int32, device=dev)
+    qsl = torch.tensor(np.concatenate([[0], np.cumsum(ql)]).astype(np.int32), device=dev)
+    out = torch.empty_like(q)
+    rs = ops.split_requests(ql, Hq // Hkv, dev)
+    run = lambda: ops.verify_attention(q, kv[0], kv[1], bt, seq, qsl, max(ql), ctx, D ** -0.5, out=out, req_split=rs)
+    us = timeit(run)
+    cap = 32768
+    buf = torch.zeros((cap, 8), dtype=torch.int64, device=dev)     # two rows of 8 per wave
+    N.lib().aic_debug_attn_phase_trace(buf.data_ptr(), cap)
+    us_tr = timeit(run)
+    N.lib().aic_debug_attn_phase_trace(None, 0)
+    t = buf.cpu().numpy().reshape(-1, 16)
+    t = t[t[:, 7] > 0]
+    n_iter, tiles = t[:, 6] >> 8, t[:, 6] & 0xff
+    dur_us = (t[:, 7] - t[:, 10]) / 100.0
+    ghz = float(np.median(t[:, 11] / np.maximum(dur_us, 1e-3))) / 1e3
+    start = (t[:, 10] - t[:, 10].min()) / 100.0
+    print(f"long-phases B={B} x {q_long} tokens, ctx {ctx}: call {us:.1f} us (traced build {us_tr:.1f} us); {len(t) // 4} workgroups, "
+          f"{int(np.median(n_iter))} KV tiles each; shader clock {ghz:.2f} GHz; wave start after the first: median {np.median(start):.1f} "
+          f"max {start.max():.1f} us; wave duration min / median / max {dur_us.min():.1f} / {np.median(dur_us):.1f} / {dur_us.max():.1f} us")
+    print("   cycles per KV tile and wave, by the wave's row tiles (MFMA issue is asynchronous: a phase that needs results waits for them)")
+    for k in sorted(set(tiles.tolist())):
+        m = tiles == k
+        it = np.maximum(n_iter[m], 1).astype(np.float64)
+        f = lambda c: float(np.median(t[m, c] / it))
+        print(f"   {k} row tiles ({m.sum():5d} waves): loop {f(1):6.0f} = vmcnt wait {f(8):5.0f} | barrier {f(9):5.0f} | next tile's DMA issued {f(2):5.0f} | "
+              f"K reads + score MFMAs issued {f(3):5.0f} | soft-max {f(4):5.0f} | V reads + PV MFMAs issued {f(5):5.0f};  prologue {float(np.median(t[m, 0])):6.0f}")
+
+
 def lstm(B, fp8=True):
     from arcticinference_amd.speculator import ArcticLSTMSpeculator, LSTMSpeculatorConfig, random_lstm_weights
     cfg = LSTMSpeculatorConfig(vocab_size=128256, input_hidden_dim=4096)
@@ -311,6 +348,10 @@ if __name__ == "__main__":
                 print(f"fp8 layout hpw={hpw} splits={sp}: ", end="")
                 attn_mix(B, 0, kv8=True)
         N.lib().aic_debug_attn_layout(0, 0)
+    if "longphases" in what:  # cycle accounting of the long-draft body
+        attn_long_phases(16, 33)
+        attn_long_phases(16, 20)
+        attn_long_phases(32, 12)
     if "phases" in what:      # in-kernel phase trace of the short body: where the per-call fixed cost sits
         for kv8 in (False, True):
             for n in (32, 64):
