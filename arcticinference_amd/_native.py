@@ -113,6 +113,7 @@ _SIGNATURES = {
     "aic_debug_attn_light": (c_int, [c_int]),
     "aic_debug_attn_graph": (c_int, [c_int]),
     "aic_debug_attn_long_splits": (c_int, [c_int]),
+    "aic_debug_attn_long_dma": (c_int, [c_int]),
     "aic_debug_attn_graph_stats": (c_int, [POINTER(c_uint64), POINTER(c_uint64)]),
     "aic_row_gather": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64),
                                POINTER(c_int32), c_void_p, c_int, c_int, c_void_p]),

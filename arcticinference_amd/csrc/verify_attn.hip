@@ -66,6 +66,7 @@ struct AttnParams {
   int num_q_heads;
   int num_kv_heads;
   int block_size;
+  int long_dma;   // long-draft body: who issues the tile DMA (aic_debug_attn_long_dma; see verify_attn_long4_body)
   int bs_shift;   // log2(block_size) when it is a power of two, else -1 (the long-draft body then divides)
   int n_splits;       // token-range splits of THIS launch
   int n_parts_total;  // partial slots per row the combine kernel reads (max over the launches of a call)
@@ -776,15 +777,17 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((M
 // chains and the VALU work of different row tiles from overlapping, and the wave (alone on its SIMD) ran at the
 // sum of every latency.
 template <int NT, int RT, int D, bool TR, int NP, typename Dma>
-__device__ __forceinline__ void long_tile_compute(const unsigned (&ka)[D / 32], const unsigned (&va)[D / 16], unsigned slot_off,
+__device__ __forceinline__ void long_tile_compute(unsigned ka0, unsigned va0, unsigned slot_off,
                                                   const uint4 (&qf)[RT][D / 32],
                                                   const bool (&row_ok)[RT], const int (&row_pos)[RT],
                                                   float (&m_run)[RT], float (&m_use)[RT], float (&thr)[RT], f32x2 (&l_run)[RT],
                                                   f32x4 (&o_acc)[RT][D / 16], int tt, int t_end, int ctx, int q_len, int wnd,
                                                   float scale_log2, float inv_scale, int g, int c16, const Dma& dma,
                                                   uint64_t* cyc = nullptr) {
-    // ka / va: this lane's LDS byte addresses of its K fragments (k-step s, tokens c16 and, 16 rows on, 16 + c16) and of its
-    // transposed V reads (output tile dt) in ring slot 0; slot_off: the tile's slot — one add per address and tile.
+    // ka0 / va0: this lane's LDS byte address of its first K fragment (k-step 0, token c16; 16 + c16 is 16 rows on) and of its
+    // first transposed V read (output tile 0) in ring slot 0.  The images' chunk swizzle is an XOR of the 16-byte chunk index
+    // with a function of the row, and the k-step / output tile sits in chunk bits the row function only XORs: k-step s is
+    // address ^ 64 s, output tile dt address ^ 32 dt (the LDS array is 1 KiB aligned) — two registers instead of twelve.
     // dma(i), i < NP: the next tile's LDS-DMA pieces of this wave, issued one by one between the row tiles' soft-max blocks
     // (VALU-only stretches) instead of back to back at the loop head
     // TR (aic_debug_attn_phase_trace on a long-only call): shader-clock cycles of this wave per phase, summed over its tiles —
@@ -798,7 +801,7 @@ __device__ __forceinline__ void long_tile_compute(const unsigned (&ka)[D / 32], 
     u32x4 kf[2][DS];
 #pragma unroll
     for (int s = 0; s < DS; ++s) {
-      const unsigned a = ka[s] + slot_off;
+      const unsigned a = (ka0 + slot_off) ^ (64u * s);
       kf[0][s] = *reinterpret_cast<lds_u4>(a);
       kf[1][s] = *reinterpret_cast<lds_u4>(a + kHalf);
     }
@@ -918,7 +921,7 @@ __device__ __forceinline__ void long_tile_compute(const unsigned (&ka)[D / 32], 
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       typedef s16x4 __attribute__((address_space(3))) * lds_tr;
-      const unsigned a = va[dt] + slot_off;
+      const unsigned a = (va0 + slot_off) ^ (32u * dt);
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_tr>(a));
       const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_tr>(a + kHalf));
       typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -1142,12 +1145,55 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
   constexpr int kPieces = ROW128 ? 2 : 4;
   constexpr int EB = KV8 ? 1 : 2;   // bytes per cache element
   const unsigned row_bytes = static_cast<unsigned>(kv_row) * EB;
+  // Who moves what (256-byte rows only).  With 4 k + 1 or 4 k + 2 row tiles the waves that hold one tile more set the pace of
+  // every iteration while the others wait at the barrier (cycle accounting: 450-800 cycles per tile), and a wave's DMA duty —
+  // page lookup, four base addresses, four LDS-DMA instructions — is ~65 instructions per tile: those waves issue NOTHING,
+  // and their quarters of the tile are moved by the lighter waves (dma_mode 0 = none, 1 = own quarter, 2 = own + donated
+  // pieces).  4 k + 1: wave 0's quarter goes to waves 1 (K lo, K hi), 2 (V lo), 3 (V hi); 4 k + 2: wave 2 moves wave 0's
+  // quarter, wave 3 wave 1's.
+  int dma_mode = 1, donor_q = 0;
+  unsigned donor_mask = 0, own_mask = 0xfu;
+  if constexpr (!ROW128) {
+    const int extra = n_row_tiles & 3;
+    const int pat = P.long_dma;   // 0 symmetric; 1: heavy waves issue nothing; 2: heavy waves keep their K pieces; 3: 4 k + 1 only, wave 0 keeps K lo
+    if (extra == 1 && pat > 0) {
+      if (wave == 0) {
+        own_mask = pat == 1 ? 0u : pat == 2 ? 0x3u : 0x1u;
+        dma_mode = own_mask ? 1 : 0;
+      } else {
+        const unsigned give = 0xfu & ~(pat == 1 ? 0u : pat == 2 ? 0x3u : 0x1u);            // what wave 0 hands over
+        const unsigned want = wave == 1 ? 0x3u : wave == 2 ? 0x4u : 0x8u;                    // K lo + K hi / V lo / V hi
+        donor_mask = give & want;
+        dma_mode = donor_mask ? 2 : 1;
+      }
+    } else if (extra == 2 && pat > 0) {
+      if (wave < 2) {
+        own_mask = pat == 1 ? 0u : 0x3u;
+        dma_mode = own_mask ? 1 : 0;
+      } else {
+        dma_mode = 2;
+        donor_q = wave - 2;
+        donor_mask = pat == 1 ? 0xfu : 0xcu;
+      }
+    }
+  }
+  const int my_pieces = __builtin_amdgcn_readfirstlane(ROW128 ? kPieces : __builtin_popcount(own_mask) + __builtin_popcount(donor_mask));
+  // per-lane byte offset of quarter q's piece from the first row of its 16-token group (rows 4 q .. 4 q + 3 of the image)
+  auto lane_off = [&](int q, int f, int tt_half, bool clamp) -> unsigned {
+    const int rq = 4 * q + g;
+    const int tq = (rq & ~12) | ((rq & 4) << 1) | ((rq & 8) >> 1);
+    const int cq = c16 ^ (((rq & 3) << 2) | ((rq >> 2) & 3));
+    const int rel = clamp ? min(tt_half + tq, ctx - 1) - f : tq;
+    return static_cast<unsigned>(rel) * row_bytes + 16u * cq;
+  };
   const unsigned loff = ROW128 ? static_cast<unsigned>(tk - 16 * (wave >> 1)) * row_bytes + 16u * ch
                                : static_cast<unsigned>(tk) * row_bytes + 16u * ch;
+  const unsigned loff_donor = ROW128 ? 0u : lane_off(donor_q, 0, 0, false);
   struct TileDma {
     const char *k0, *k1, *v0, *v1;
-    unsigned l0, l1, slot;
-    bool on;
+    unsigned l0, slot;      // ROW128: this wave's lane offset; slot: LDS address of the tile's image (256-byte rows: without the wave's rows)
+    int tt, f0, f1;         // 256-byte rows: the tile's first token and its two groups' first tokens
+    bool full, on;
   } td;
   td.on = false;
   const uint64_t stride_bytes = static_cast<uint64_t>(P.block_stride) * EB;
@@ -1162,42 +1208,50 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
     constexpr bool kSteady = decltype(steady)::value;
     const int tt = t_begin + jt * kTile;
     td.on = true;
-    const bool full = kSteady || tt + kTile <= ctx;
+    td.full = kSteady || tt + kTile <= ctx;
     if constexpr (ROW128) {
       const int f = min(tt + 16 * (wave >> 1), last_group);   // tokens 0-15 / 16-31 of the tile: one page per wave
       const uint64_t b = group_base(pa, static_cast<unsigned>(f));
       td.k0 = kc + b;
       td.v0 = vc + b;
-      td.l0 = full ? loff : static_cast<unsigned>(min(tt + tk, ctx - 1) - f) * row_bytes + 16u * ch;
+      td.l0 = td.full ? loff : static_cast<unsigned>(min(tt + tk, ctx - 1) - f) * row_bytes + 16u * ch;
       td.slot = lds0 + static_cast<unsigned>(jt & (kLongRing - 1)) * kRawSlot + 1024 * wave;
     } else {
-      const int f0 = kSteady ? tt : min(tt, last_group), f1 = kSteady ? tt + 16 : min(tt + 16, last_group);
-      const uint64_t b0 = group_base(pa, static_cast<unsigned>(f0)), b1 = group_base(pb, static_cast<unsigned>(f1));
+      td.tt = tt;
+      td.f0 = kSteady ? tt : min(tt, last_group);
+      td.f1 = kSteady ? tt + 16 : min(tt + 16, last_group);
+      const uint64_t b0 = group_base(pa, static_cast<unsigned>(td.f0)), b1 = group_base(pb, static_cast<unsigned>(td.f1));
       td.k0 = kc + b0;
       td.k1 = kc + b1;
       td.v0 = vc + b0;
       td.v1 = vc + b1;
-      td.l0 = full ? loff : static_cast<unsigned>(min(tt + tk, ctx - 1) - f0) * row_bytes + 16u * ch;
-      td.l1 = full ? loff : static_cast<unsigned>(min(tt + 16 + tk, ctx - 1) - f1) * row_bytes + 16u * ch;
-      td.slot = lds0 + static_cast<unsigned>(jt & (kLongRing - 1)) * (2 * kImg) + 1024 * wave;
+      td.slot = lds0 + static_cast<unsigned>(jt & (kLongRing - 1)) * (2 * kImg);
     }
   };
-  auto piece = [&](int i) {          // i is a compile-time constant at every call site
+  // piece i of the tile prepared last (i is a compile-time constant at every call site): 0-3 = this wave's quarter
+  // (K lo, K hi, V lo, V hi), 4-7 = the same of the donor quarter where donor_mask has the bit
+  auto piece = [&](int i) {
     if (!td.on) return;
     if constexpr (ROW128) {
       if (i == 0) glds16s(td.k0, td.l0, td.slot);
       else if (i == 1) glds16s(td.v0, td.l0, td.slot + kRawSlot / 2);
     } else {
-      if (i == 0) glds16s(td.k0, td.l0, td.slot);
-      else if (i == 1) glds16s(td.k1, td.l1, td.slot + 4096);
-      else if (i == 2) glds16s(td.v0, td.l0, td.slot + kImg);
-      else if (i == 3) glds16s(td.v1, td.l1, td.slot + kImg + 4096);
+      const int kind = i & 3;
+      const bool donated = i >= 4;
+      if (!(((donated ? donor_mask : own_mask) >> kind) & 1u)) return;
+      const int q = donated ? donor_q : wave;
+      const bool hi = kind & 1;
+      unsigned off = donated ? loff_donor : loff;
+      if (!td.full) off = lane_off(q, hi ? td.f1 : td.f0, td.tt + (hi ? 16 : 0), true);   // the context's last tile: rows clamp
+      const char* base = kind == 0 ? td.k0 : kind == 1 ? td.k1 : kind == 2 ? td.v0 : td.v1;
+      glds16s(base, off, td.slot + 1024u * q + (hi ? 4096u : 0u) + (kind >= 2 ? static_cast<unsigned>(kImg) : 0u));
     }
   };
   auto issue = [&](int jt, int pa, int pb) {
+    if (dma_mode == 0) return;
     prep(jt, pa, pb, std::false_type{});
 #pragma unroll
-    for (int i = 0; i < kPieces; ++i) piece(i);
+    for (int i = 0; i < 2 * kPieces; ++i) piece(i);
     td.on = false;
   };
   // fp8: this wave's quarter of raw tile jt -> bf16 image jt & 1
@@ -1212,21 +1266,21 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
     *reinterpret_cast<bf16x8*>(vb + tile_off<D>(tk, 2 * ch)) = fp8x8_to_bf16x8(v8.x, v8.y);
     *reinterpret_cast<bf16x8*>(vb + tile_off<D>(tk, 2 * ch + 1)) = fp8x8_to_bf16x8(v8.z, v8.w);
   };
-  // wait until at most `tiles` of this wave's most recent tile loads are still in flight (DMAs retire in order)
+  // wait until at most `tiles` of this wave's most recent tile loads are still in flight (DMAs retire in order); a tile is
+  // my_pieces instructions of this wave (0, 2, 4, 5, 6 or 8)
   auto wait_tiles = [&](int tiles) {
-    constexpr int per = ROW128 ? 2 : 4;
-    if (tiles >= 3) {
-      if (per == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    } else if (tiles == 2) {
-      if (per == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else if (tiles == 1) {
-      if (per == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    const int n = tiles * my_pieces;
+    if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (n >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n >= 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (n >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   constexpr int kAhead = KV8 ? kLongRing : kLongAhead;   // tiles issued before the loop
   asm volatile("" : "+v"(vpages));   // (a compiler-counted load, like Q: retired before the first DMA is in flight)
@@ -1244,22 +1298,17 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
     convert(0);
   }
 
-  // LDS addresses of this lane's fragment reads in image slot 0 (long_tile_compute adds the tile's slot)
-  unsigned ka[DS], va[DT];
-  {
-    const unsigned img0 = lds0 + kImgBase;
-#pragma unroll
-    for (int s = 0; s < DS; ++s) ka[s] = img0 + tile_off<D>(c16, 4 * s + g);
-    const int q4 = c16 >> 2, p4 = c16 & 3;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) va[dt] = img0 + kImg + tile_off<D>(4 * g + q4, 2 * dt + (p4 >> 1)) + 8 * (p4 & 1);
-  }
+  // LDS addresses of this lane's first K fragment and first transposed V read in image slot 0 (see long_tile_compute)
+  const unsigned ka0 = lds0 + kImgBase + tile_off<D>(c16, g);
+  const unsigned va0 = lds0 + kImgBase + kImg + tile_off<D>(4 * g + (c16 >> 2), (c16 & 3) >> 1) + 8 * (c16 & 1);
   uint64_t c_loop = 0;
   if constexpr (TR) c_loop = __builtin_amdgcn_s_memtime();
   // One iteration = one KV tile.  `steady` iterations (bf16 cache: those whose issued tile it + 3 is not the last of the range)
-  // run with constant waits and unclamped addresses; the last four take the general form.
-  auto tile_iter = [&](int it, auto nt_tag, auto steady) {
+  // run with constant waits and unclamped addresses; the last four take the general form.  np_tag: the DMA pieces this wave
+  // may issue per tile (0: none, kPieces: its quarter, 2 kPieces: its quarter + donated pieces).
+  auto tile_iter = [&](int it, auto nt_tag, auto np_tag, auto steady) {
     constexpr int NT = decltype(nt_tag)::value;
+    constexpr int NPT = decltype(np_tag)::value;
     constexpr bool kSteady = decltype(steady)::value;
     uint64_t c_top = 0;
     if constexpr (TR) c_top = __builtin_amdgcn_s_memtime();
@@ -1276,8 +1325,14 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
       if (it + 1 < n_iter) convert(it + 1);
     } else {
       // tile `it` has landed when at most the tiles issued after it are still outstanding
-      if constexpr (kSteady) wait_tiles(2);
-      else wait_tiles(min(2, n_iter - 1 - it));
+      if constexpr (NPT > 0) {
+        if constexpr (!kSteady) {
+          wait_tiles(min(2, n_iter - 1 - it));
+        } else {
+          if (my_pieces == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          else wait_tiles(2);
+        }
+      }
       if constexpr (TR) {
         const uint64_t c = __builtin_amdgcn_s_memtime();
         cyc[4] += c - c_top;
@@ -1291,14 +1346,16 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
         c_top = c;
       }
       td.on = false;
-      if (kSteady || it + kLongAhead < n_iter) {
-        int pa, pb;
-        pages(it + kLongAhead, pa, pb, steady);
-        prep(it + kLongAhead, pa, pb, steady);
-      }
-      if constexpr (NT == 0) {      // a wave without rows: nothing to spread the pieces over
+      if constexpr (NPT > 0) {
+        if (kSteady || it + kLongAhead < n_iter) {
+          int pa, pb;
+          pages(it + kLongAhead, pa, pb, steady);
+          prep(it + kLongAhead, pa, pb, steady);
+        }
+        if constexpr (NT == 0) {      // a wave without rows: nothing to spread the pieces over
 #pragma unroll
-        for (int i = 0; i < kPieces; ++i) piece(i);
+          for (int i = 0; i < NPT; ++i) piece(i);
+        }
       }
     }
     if constexpr (TR) cyc[0] += __builtin_amdgcn_s_memtime() - c_top;
@@ -1307,18 +1364,33 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
       auto dma = [&](int i) {
         if constexpr (!KV8) piece(i);   // (fp8: the tile's DMA went out at the loop head, before the conversion)
       };
-      long_tile_compute<NT, RT, D, TR, KV8 ? 0 : kPieces>(ka, va, slot_off, qf, row_ok, row_pos, m_run, m_use, thr, l_run, o_acc,
-                                                           t_begin + it * kTile, t_end, ctx, q_len, wnd, scale_log2, inv_scale,
-                                                           g, c16, dma, cyc);
+      long_tile_compute<NT, RT, D, TR, KV8 ? 0 : NPT>(ka0, va0, slot_off, qf, row_ok, row_pos, m_run, m_use, thr, l_run, o_acc,
+                                                       t_begin + it * kTile, t_end, ctx, q_len, wnd, scale_log2, inv_scale,
+                                                       g, c16, dma, cyc);
     }
   };
-  auto tile_loop = [&](auto nt_tag) {
+  auto tile_loop_np = [&](auto nt_tag, auto np_tag) {
     int it = 0;
     if constexpr (!KV8) {
       const int n_steady = n_iter - 1 - kLongAhead;   // issued tile it + 3 <= n_iter - 2
-      for (; it < n_steady; ++it) tile_iter(it, nt_tag, std::true_type{});
+      for (; it < n_steady; ++it) tile_iter(it, nt_tag, np_tag, std::true_type{});
     }
-    for (; it < n_iter; ++it) tile_iter(it, nt_tag, std::false_type{});
+    for (; it < n_iter; ++it) tile_iter(it, nt_tag, np_tag, std::false_type{});
+  };
+  auto tile_loop = [&](auto nt_tag) {
+    constexpr int NT = decltype(nt_tag)::value;
+    if constexpr (ROW128) {
+      tile_loop_np(nt_tag, std::integral_constant<int, kPieces>{});
+    } else {
+      // (a wave that issues nothing holds at least one row tile; one that takes donated pieces at most RT - 1)
+      if (NT >= 1 && dma_mode == 0) {
+        if constexpr (NT >= 1) tile_loop_np(nt_tag, std::integral_constant<int, 0>{});
+      } else if (NT < RT && dma_mode == 2) {
+        if constexpr (NT < RT) tile_loop_np(nt_tag, std::integral_constant<int, 2 * kPieces>{});
+      } else {
+        tile_loop_np(nt_tag, std::integral_constant<int, kPieces>{});
+      }
+    }
   };
   if (my_tiles >= 3) {
     tile_loop(std::integral_constant<int, 3>{});
@@ -1378,7 +1450,7 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
 
 template <bool KV8, int D = 128, bool TR = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) verify_attn_long4_kernel(AttnParams P) {
-  __shared__ uint4 lds[kLong4LdsU4];
+  __shared__ __attribute__((aligned(1024))) uint4 lds[kLong4LdsU4];
   verify_attn_long4_body<KV8, D, TR>(P, lds, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
@@ -1392,7 +1464,7 @@ template <int HPW, bool KV8, int MTQ>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 verify_attn_pair_kernel(AttnParams PS, AttnParams PL, int n_long_wg, int n_long_pad, int long_x, int long_y, int short_x) {
   constexpr int kShortU4 = ShortLds<MTQ == 0 ? 2 : MTQ, 4>::kU4;
-  __shared__ uint4 lds[kLong4LdsU4 > kShortU4 ? kLong4LdsU4 : kShortU4];
+  __shared__ __attribute__((aligned(1024))) uint4 lds[kLong4LdsU4 > kShortU4 ? kLong4LdsU4 : kShortU4];
   const int b = blockIdx.x;
   int64_t t0 = 0;
   if (PS.trace) t0 = static_cast<int64_t>(__builtin_amdgcn_s_memrealtime());
@@ -1626,6 +1698,7 @@ static int64_t* g_attn_trace = nullptr;
 static int g_attn_trace_cap = 0;
 static int64_t* g_attn_ptrace = nullptr;   // aic_debug_attn_phase_trace
 static int g_attn_ptrace_cap = 0;
+static int g_long_dma = 1;    // aic_debug_attn_long_dma: AttnParams.long_dma
 static int g_long_splits = 0; // aic_debug_attn_long_splits: split count of the long-draft part of a mixed call (0 = the default)
 static int g_light_pct = 0;   // aic_debug_attn_light: weight of the light splits in percent (0 = the default, 100 = off)
 static int g_force_hpw = 0, g_force_splits = 0;   // aic_debug_attn_layout (tools/microbench.py sweeps); 0 = choose
@@ -1841,6 +1914,7 @@ int aic_verify_attention_win(const void* q, int64_t q_stride, const void* k_cach
   P.num_q_heads = num_q_heads;
   P.num_kv_heads = num_kv_heads;
   P.block_size = block_size;
+  P.long_dma = g_long_dma;
   P.bs_shift = (block_size & (block_size - 1)) == 0 ? __builtin_ctz(static_cast<unsigned>(block_size)) : -1;
   P.n_splits = n_splits;
   P.n_parts_total = n_parts_total;
@@ -2167,6 +2241,11 @@ static int replay_as_graph(const Recorder& rec, hipStream_t s) {
 }
 
 // 0: kernel-by-kernel launches only; 1 (default): runs of >= 4 layers go out as one graph launch.
+int aic_debug_attn_long_dma(int pattern) {
+  AIC_REQUIRE(pattern >= 0 && pattern <= 3, "bad pattern");
+  g_long_dma = pattern;
+  return AIC_OK;
+}
 int aic_debug_attn_long_splits(int splits) {
   AIC_REQUIRE(splits >= 0 && splits <= 64, "bad split count");
   g_long_splits = splits;

@@ -198,6 +198,9 @@ int aic_debug_attn_light(int pct);
 /* debug aid: upper bound on the cross-workgroup split count of the long-draft part of a mixed call (0 = chosen by the
  * library); every setting computes the same result. */
 int aic_debug_attn_long_splits(int splits);
+/* debug: which waves of a long-draft workgroup issue the tile DMA when the row tiles do not divide by four (0 = every wave its
+ * quarter, 1 = the waves with one row tile more issue nothing, 2 = they keep their K pieces, 3 = wave 0 keeps one piece). */
+int aic_debug_attn_long_dma(int pattern);
 /* aic_verify_attention_layers sends a run of >= 4 layers out as HIP graph launches (an instantiated graph per sequence of
  * kernels, its nodes' parameters rewritten per call; 12 layers or more: the first 4 as one graph, the rest as a second)
  * unless the stream is being captured by the caller.  0 switches that off (kernel-by-kernel launches), 1 (default) on,

@@ -348,6 +348,15 @@ if __name__ == "__main__":
                 print(f"fp8 layout hpw={hpw} splits={sp}: ", end="")
                 attn_mix(B, 0, kv8=True)
         N.lib().aic_debug_attn_layout(0, 0)
+    if "longdma" in what:     # who issues the tile DMA in a long-draft workgroup (aic_debug_attn_long_dma)
+        for pat in (0, 1, 2, 3):
+            N.lib().aic_debug_attn_long_dma(pat)
+            print(f"-- long_dma pattern {pat}")
+            for B, q in ((16, 33), (16, 20), (16, 24), (32, 12), (16, 6)):
+                attn(B=B, ctx=4096, qlen=q, split=True)
+            attn_mix(31, 1, q_long=33)
+            attn_mix(28, 4, q_long=20)
+        N.lib().aic_debug_attn_long_dma(1)
     if "longphases" in what:  # cycle accounting of the long-draft body
         attn_long_phases(16, 33)
         attn_long_phases(16, 20)
@@ -425,6 +434,10 @@ if __name__ == "__main__":
             attn_ql([1] * 62 + [20] * 2, jitter=jit)
             attn_ql([1] * 63 + [33], jitter=jit)
             attn_ql([1] * 58 + [5, 7, 8, 10, 20, 33], jitter=jit)
+    if "trace32" in what:      # one lane of the bench: 32 requests, a few long drafts
+        attn_trace(31, 1)
+        attn_trace(28, 4, q_long=20)
+        attn_trace(27, 5)
     if "trace" in what:
         attn_trace(59, 5)
         attn_trace(56, 8)
@@ -452,6 +465,14 @@ if __name__ == "__main__":
         attn_mix(59, 5, kv8=True)
         attn_mix(8, 1, Hq=4, Hkv=1)      # SP = 8 slice
         attn_mix(59, 5, Hq=4, Hkv=1)
+    if "longsplits8" in what:   # the same at full width (8 kv heads: one GPU), after the r04 long-body changes
+        L = N.lib()
+        for ns, nl, ql in ((31, 1, 33), (30, 2, 33), (28, 4, 20), (27, 5, 33), (25, 7, 20)):
+            for sp in (0, 3, 4, 5, 6, 8, 10):
+                L.aic_debug_attn_long_splits(sp)
+                print("long splits %2d: " % sp, end="")
+                attn_mix(ns, nl, q_long=ql)
+        L.aic_debug_attn_long_splits(0)
     if "longsplits" in what:
         # long-draft split count of a mixed call on the slices a rank sees under SP (kv heads per rank 8 / 4 / 2 / 1)
         L = N.lib()
