@@ -457,13 +457,32 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
     int first0, first1;    // first token of each group (clamped into the context)
   };
   const int last_group = (ctx - 1) & ~15;
+  // (unsigned 32-bit page arithmetic, a shift for power-of-two pages: the signed divisions and 64-bit products this replaced
+  // were ~50 of the loop's ~135 scalar instructions per tile, and a scalar instruction costs a lone wave 7-8 cycles —
+  // tools/exp/salu_rate.hip — in a loop whose fp8 form is issue-bound)
+  const int bsh = P.bs_shift;
+  const unsigned kv_row32 = static_cast<unsigned>(kv_row), head_off = static_cast<unsigned>(h * HD);
+  const uint64_t block_stride_u = static_cast<uint64_t>(P.block_stride);
   auto tile_pages = [&](int tt) -> TilePages {
     TilePages tp;
     tp.first0 = min(tt, last_group);
     tp.first1 = min(tt + 16, last_group);
-    const int b0 = btab[tp.first0 / bs], b1 = btab[tp.first1 / bs];
-    tp.base0 = static_cast<int64_t>(b0) * P.block_stride + static_cast<int64_t>(tp.first0 % bs) * kv_row + h * HD;
-    tp.base1 = static_cast<int64_t>(b1) * P.block_stride + static_cast<int64_t>(tp.first1 % bs) * kv_row + h * HD;
+    const unsigned f0 = static_cast<unsigned>(tp.first0), f1 = static_cast<unsigned>(tp.first1);
+    unsigned pg0, pg1, po0, po1;
+    if (bsh >= 0) {
+      pg0 = f0 >> bsh;
+      pg1 = f1 >> bsh;
+      po0 = f0 & static_cast<unsigned>(bs - 1);
+      po1 = f1 & static_cast<unsigned>(bs - 1);
+    } else {
+      pg0 = f0 / static_cast<unsigned>(bs);
+      pg1 = f1 / static_cast<unsigned>(bs);
+      po0 = f0 - pg0 * static_cast<unsigned>(bs);
+      po1 = f1 - pg1 * static_cast<unsigned>(bs);
+    }
+    const unsigned b0 = static_cast<unsigned>(btab[pg0]), b1 = static_cast<unsigned>(btab[pg1]);
+    tp.base0 = static_cast<int64_t>(b0 * block_stride_u + (po0 * kv_row32 + head_off));
+    tp.base1 = static_cast<int64_t>(b1 * block_stride_u + (po1 * kv_row32 + head_off));
     return tp;
   };
 
