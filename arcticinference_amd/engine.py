@@ -405,6 +405,8 @@ class HotPathEngine:
         oa, ob = L.offs_a, L.offs_b
         if getattr(self, "qlen_hist", None) is not None:      # diagnostic (bench.py --qlen-hist): query lengths seen
             self.qlen_hist += np.bincount(n_draft + 1, minlength=len(self.qlen_hist))[:len(self.qlen_hist)]
+            if getattr(self, "mix_log", None) is not None:   # which long drafts share a lane step (the attention call's mix)
+                self.mix_log.append(tuple(sorted(int(q) + 1 for q in n_draft if (int(q) + 1) * G > 32)))
         # Phase streams (interleaved lanes only): the step's small launches before the attention — staging copy, block-table
         # gather, KV write — are each a few microseconds of GPU work with 15-40 us of queue latency between them
         # (rocprofv3 timeline, profiles/r03_step_timeline.txt: 0.29 ms of idle queue per round).  On a stream of their own
@@ -507,6 +509,8 @@ class HotPathEngine:
         max_q, max_ctx = int(q_len.max()), int(ctx.max())
         if getattr(self, "qlen_hist", None) is not None:      # diagnostic (bench.py --qlen-hist): query lengths seen
             self.qlen_hist += np.bincount(q_len, minlength=len(self.qlen_hist))[:len(self.qlen_hist)]
+            if getattr(self, "mix_log", None) is not None:   # which long drafts share a lane step (the attention call's mix)
+                self.mix_log.append(tuple(sorted(int(q) for q in q_len if q * G > 32)))
 
         # Two staging copies per step.  (A) what the KV write and the attention launches need — contexts, query offsets,
         # slots, the short / long request lists — goes first, and the 2 x L launches are enqueued right behind it.  (B) what

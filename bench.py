@@ -24,6 +24,7 @@ exits with their code.  Rank 0 prints ONE JSON line.
 from __future__ import annotations
 
 import argparse
+import collections
 import json
 import os
 import sys
@@ -484,6 +485,7 @@ def main():
     eng.timeline = {}
     if args.qlen_hist:
         eng.qlen_hist = np.zeros(40, dtype=np.int64)
+        eng.mix_log = []
     if ulysses is not None:
         ulysses.steps_sp = ulysses.steps_shift = 0
     if drafter is not None:
@@ -716,7 +718,9 @@ def main():
                                      if suffix_owner is not None else "replicated on every rank (the reference's arrangement)"),
             "draft_model_policy": ("per request (extension)" if spec.draft_model_per_request else
                                    "reference rule: no draft-model proposal in a step where suffix decoding takes a request"),
-            **({"query_len_histogram": {str(i): int(c) for i, c in enumerate(eng.qlen_hist) if c}} if args.qlen_hist else {}),
+            **({"query_len_histogram": {str(i): int(c) for i, c in enumerate(eng.qlen_hist) if c},
+                "long_drafts_per_lane_step": [[list(k), v] for k, v in collections.Counter(eng.mix_log).most_common(24)]}
+               if args.qlen_hist else {}),
             "steps_with_draft_model": st.draft_model_steps, "draft_model_launches_dropped": st.draft_model_dropped,
             "draft_acceptance_rate": st.accepted / max(st.drafted, 1),
             "tokens_per_request_step": st.emitted / max(args.steps * B, 1),
