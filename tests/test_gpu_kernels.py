@@ -253,6 +253,8 @@ def _attn_case(B, Hq, Hkv, D, q_lens, ctxs, bs, seed):
     dict(B=40, Hq=32, Hkv=8, q_lens=[4] * 30 + [12, 33, 7, 20, 9, 33, 5, 16, 11, 6], ctxs=[260 + 37 * i for i in range(40)], bs=16),  # many items: the one-launch form does not fit, two launches
     dict(B=3, Hq=32, Hkv=8, q_lens=[50, 4, 63], ctxs=[640, 64, 2049], bs=64),          # block_size 64; 200 and 252 rows: two 192-row groups
     dict(B=2, Hq=8, Hkv=2, q_lens=[4, 1], ctxs=[128, 256], bs=128),                      # block_size 128, contexts at tile / page boundaries
+    dict(B=5, Hq=32, Hkv=8, q_lens=[4, 33, 1, 20, 24], ctxs=[700, 1300, 95, 2100, 333], bs=48),  # pages of 48 tokens: not a power of two (the bodies divide instead of shifting)
+    dict(B=4, Hq=32, Hkv=8, q_lens=[18, 33, 22, 36], ctxs=[1100, 1057, 2079, 97], bs=16),   # 5 / 9 / 6 / 9 row tiles: waves with one tile more issue no DMA; contexts end inside a tile
 ])
 def test_verify_attention(cfg):
     D = 128
@@ -1024,6 +1026,39 @@ def test_verify_attention_mixed_call_forms_agree(seed):
             assert torch.allclose(got, generic, atol=1e-3, rtol=2 ** -7), (seed, B, Hkv, n_long, mode, float((got - generic).abs().max()))
     finally:
         N.check(N.lib().aic_debug_attn_sequential(-1))
+
+
+def test_verify_attention_long_draft_dma_duty_patterns():
+    """Who issues the tile DMA in a long-draft workgroup is a choice (aic_debug_attn_long_dma: every wave its quarter / the waves
+    with one row tile more issue nothing / they keep their K pieces / wave 0 keeps one piece): every pattern must give the same
+    attention, long drafts alone and beside short requests, at 5, 6, 9 and 10 row tiles (17-20, 21-24, 33-36, 37-40 tokens at
+    G = 4), contexts that end inside a tile and inside a page, against the oracle."""
+    from arcticinference_amd import _native as N
+    B, Hq, Hkv, D, bs = 9, 32, 8, 128, 16
+    q_lens = [17, 20, 22, 24, 33, 36, 38, 1, 4]
+    ctxs = [1100, 97, 2079, 513, 1057, 4100, 640, 300, 77]
+    q, kc, vc, bt, qsl = _attn_case(B, Hq, Hkv, D, q_lens, ctxs, bs, seed=11)
+    want = O.verify_attention(q, kc, vc, bt, ctxs, qsl, D ** -0.5)
+    seq = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
+    outs = {}
+    try:
+        for pat in (0, 1, 2, 3):
+            N.lib().aic_debug_attn_long_dma(pat)
+            outs[pat] = _ops().verify_attention(q.to(DEV), kc.to(DEV), vc.to(DEV), bt.to(DEV), seq, torch.tensor(qsl, device=DEV),
+                                                max(q_lens), max(ctxs), D ** -0.5, q_lens_host=q_lens).float().cpu()
+    finally:
+        N.lib().aic_debug_attn_long_dma(1)
+    for pat, got in outs.items():
+        assert torch.allclose(got, want, atol=1e-3, rtol=2 ** -8), (pat, (got - want).abs().max())
+        assert torch.equal(got, outs[1]), pat          # the same arithmetic in the same order: only the data movement differs
+    # long drafts alone (the two-launch / long-only form)
+    sel = [i for i, ql in enumerate(q_lens) if ql > 8]
+    rows = np.concatenate([np.arange(qsl[i], qsl[i + 1]) for i in sel])
+    ql2 = [q_lens[i] for i in sel]
+    qsl2 = np.concatenate([[0], np.cumsum(ql2)]).astype(np.int32)
+    got = _ops().verify_attention(q[rows].to(DEV), kc.to(DEV), vc.to(DEV), bt[sel].to(DEV), seq[sel], torch.tensor(qsl2, device=DEV),
+                                  max(ql2), max(ctxs), D ** -0.5, q_lens_host=ql2).float().cpu()
+    assert torch.allclose(got, want[rows], atol=1e-3, rtol=2 ** -8), (got - want[rows]).abs().max()
 
 
 @pytest.mark.parametrize("Hkv", [8, 1])
