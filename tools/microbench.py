@@ -467,8 +467,8 @@ if __name__ == "__main__":
         attn_mix(59, 5, Hq=4, Hkv=1)
     if "longsplits8" in what:   # the same at full width (8 kv heads: one GPU), after the r04 long-body changes
         L = N.lib()
-        for ns, nl, ql in ((31, 1, 33), (30, 2, 33), (28, 4, 20), (27, 5, 33), (25, 7, 20)):
-            for sp in (0, 3, 4, 5, 6, 8, 10):
+        for ns, nl, ql in ((31, 1, 10), (30, 2, 10), (31, 1, 20), (30, 2, 20), (31, 1, 33), (30, 2, 33), (28, 4, 20), (27, 5, 33), (25, 7, 20)):
+            for sp in (0, 2, 3, 4, 5, 6, 8, 10):
                 L.aic_debug_attn_long_splits(sp)
                 print("long splits %2d: " % sp, end="")
                 attn_mix(ns, nl, q_long=ql)
