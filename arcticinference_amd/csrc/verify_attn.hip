@@ -492,12 +492,15 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
   uint4 k00, k01, k02, k03, k10, k11, k12, k13;  // k<th><s>
   uint4 v0, v1, v2, v3, v4, v5, v6, v7;          // v<iv>
   if (ROW128) k02 = k03 = k12 = k13 = v4 = v5 = v6 = v7 = make_uint4(0, 0, 0, 0);
+  // (addresses = a wave-uniform 64-bit base per 16-token group + a 32-bit per-lane offset, a 24-bit multiply: the 64-bit
+  // per-lane products this replaced were ~18 quarter-rate instructions per tile in the fp8 body, which is issue-bound)
+  const unsigned row_bytes = static_cast<unsigned>(kv_row) * ES;
 #define AIC_LOAD_K(tt_, tp_)                                                                                   \
   {                                                                                                            \
-    const int off0_ = min((tt_) + c16, ctx - 1) - (tp_).first0;                                                \
-    const int off1_ = min((tt_) + 16 + c16, ctx - 1) - (tp_).first1;                                           \
-    const char* kp0_ = kc + ((tp_).base0 + static_cast<int64_t>(off0_) * kv_row) * ES + 16 * g;                \
-    const char* kp1_ = kc + ((tp_).base1 + static_cast<int64_t>(off1_) * kv_row) * ES + 16 * g;                \
+    const unsigned off0_ = static_cast<unsigned>(min((tt_) + c16, ctx - 1) - (tp_).first0);                    \
+    const unsigned off1_ = static_cast<unsigned>(min((tt_) + 16 + c16, ctx - 1) - (tp_).first1);               \
+    const char* kp0_ = kc + (tp_).base0 * ES + static_cast<size_t>(__umul24(off0_, row_bytes) + 16u * g);      \
+    const char* kp1_ = kc + (tp_).base1 * ES + static_cast<size_t>(__umul24(off1_, row_bytes) + 16u * g);      \
     k00 = ld_kv16(kp0_);                                                               \
     k01 = ld_kv16(kp0_ + 64);                                                          \
     k10 = ld_kv16(kp1_);                                                               \
@@ -511,10 +514,10 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
   }
   // bf16: instruction iv moves tokens 4 iv + g, 16-byte chunk c16;  fp8: tokens 8 iv + lane/8, chunk lane%8
 #define AIC_V_ADDR(tt_, tp_, iv_)                                                                              \
-  (ROW128 ? vc + (((iv_) >= 2 ? (tp_).base1 : (tp_).base0) +                                                    \
-             static_cast<int64_t>(min((tt_) + 8 * (iv_) + (lane >> 3), ctx - 1) - ((iv_) >= 2 ? (tp_).first1 : (tp_).first0)) * kv_row) * ES + 16 * (lane & 7) \
-       : vc + (((iv_) >= 4 ? (tp_).base1 : (tp_).base0) +                                                       \
-               static_cast<int64_t>(min((tt_) + 4 * (iv_) + g, ctx - 1) - ((iv_) >= 4 ? (tp_).first1 : (tp_).first0)) * kv_row) * 2 + 16 * c16)
+  (ROW128 ? vc + ((iv_) >= 2 ? (tp_).base1 : (tp_).base0) * ES +                                                \
+             static_cast<size_t>(__umul24(static_cast<unsigned>(min((tt_) + 8 * (iv_) + (lane >> 3), ctx - 1) - ((iv_) >= 2 ? (tp_).first1 : (tp_).first0)), row_bytes) + 16u * (lane & 7)) \
+       : vc + ((iv_) >= 4 ? (tp_).base1 : (tp_).base0) * 2 +                                                    \
+               static_cast<size_t>(__umul24(static_cast<unsigned>(min((tt_) + 4 * (iv_) + g, ctx - 1) - ((iv_) >= 4 ? (tp_).first1 : (tp_).first0)), row_bytes) + 16u * c16))
 #define AIC_LOAD_V(tt_, tp_)                                                                                   \
   {                                                                                                            \
     v0 = ld_kv16(AIC_V_ADDR(tt_, tp_, 0));                                             \

@@ -465,6 +465,10 @@ if __name__ == "__main__":
         attn_mix(59, 5, kv8=True)
         attn_mix(8, 1, Hq=4, Hkv=1)      # SP = 8 slice
         attn_mix(59, 5, Hq=4, Hkv=1)
+    if "mixes" in what:         # the bench's common lane mixes under the library's own rules
+        attn(B=32, ctx=4224, qlen=1, split=True)
+        for ns, nl, ql in ((31, 1, 10), (30, 2, 10), (31, 1, 20), (30, 2, 20), (31, 1, 33), (30, 2, 33), (28, 4, 20), (27, 5, 33), (25, 7, 20)):
+            attn_mix(ns, nl, q_long=ql)
     if "longsplits8" in what:   # the same at full width (8 kv heads: one GPU), after the r04 long-body changes
         L = N.lib()
         for ns, nl, ql in ((31, 1, 10), (30, 2, 10), (31, 1, 20), (30, 2, 20), (31, 1, 33), (30, 2, 33), (28, 4, 20), (27, 5, 33), (25, 7, 20)):
