@@ -134,62 +134,6 @@ __device__ __forceinline__ int v_tile_off(int t, int ch) {
 // eight workgroups at eight different times).  !WH (Hkv not a multiple of 4, e.g. one kv head per rank under
 // SP=8, where rows are contiguous anyway): the four waves split the token range of one head and are merged
 // through LDS at the end.
-// Online-softmax update of one 16-row query tile against one 32-token KV tile, in the S^T layout: the lane owns
-// query row c16 and the 8 tokens tt + 16 th + 4 g + e.  Scores are kept in the log2 domain (scale folded with
-// log2 e, v_exp_f32 is base 2).  Masking runs only on tiles that touch the causal edge or the end of the
-// range, and the O rescale only when some row's maximum moved: at 33-token drafts this VALU work, not HBM,
-// bounds the long-draft kernel.  Produces P as bf16 head + tail fragments (B operand of O^T = V^T P^T).
-template <int DT>
-__device__ __forceinline__ void softmax_tile(const f32x4& s0, const f32x4& s1, bool need_mask, bool row_ok, int tt,
-                                             int g, int t_end, int limit, int wnd, float scale_log2, float& m_run,
-                                             float& l_run, f32x4 (&o)[DT], bf16x8& pf, bf16x8& pl) {
-  float sc[8];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    sc[e] = s0[e] * scale_log2;
-    sc[4 + e] = s1[e] * scale_log2;
-  }
-  if (need_mask) {
-#pragma unroll
-    for (int th = 0; th < 2; ++th)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int tok = tt + 16 * th + 4 * g + e;
-        if (!(row_ok && tok < t_end && tok <= limit && tok > limit - wnd)) sc[th * 4 + e] = -INFINITY;
-      }
-  }
-  float tmax = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
-  tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-  tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-  const float m_new = fmaxf(m_run, tmax);
-  float alpha = 1.0f, psum = 0.0f;
-  float pv[8];
-  if (m_new == -INFINITY) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) pv[e] = 0.0f;
-  } else {
-    alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      pv[e] = __builtin_amdgcn_exp2f(sc[e] - m_new);
-      psum += pv[e];
-    }
-  }
-  psum += __shfl_xor(psum, 16);
-  psum += __shfl_xor(psum, 32);
-  l_run = l_run * alpha + psum;
-  m_run = m_new;
-  if (!__all(alpha == 1.0f)) {
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) o[dt] *= alpha;
-  }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    pf[e] = static_cast<__bf16>(pv[e]);
-    pl[e] = static_cast<__bf16>(pv[e] - static_cast<float>(pf[e]));
-  }
-}
-
 // Image of a 32-token tile for head size D: D = 128 is v_tile_off; D = 64 (128-byte rows, 8 chunks) XORs the chunk
 // with the row (the secondary head size: correct and DMA-fillable first, bank-optimal second).
 template <int D>
@@ -240,6 +184,63 @@ __device__ __forceinline__ float rowgroup_sum(float x) {
   b = a;
   swap32(a, b);
   return a + b;
+}
+
+// Online-softmax update of one 16-row query tile against one 32-token KV tile, in the S^T layout: the lane owns
+// query row c16 and the 8 tokens tt + 16 th + 4 g + e.  Scores stay raw; the scale (folded with log2 e, v_exp_f32 is base 2)
+// enters the exponent's fma.  Produces P as bf16 head + tail fragments (B operand of O^T = V^T P^T).
+// r04: the row maximum is LAZY, as in the long-draft body — a row keeps the maximum it last adopted (m_run, scaled; -inf =
+// nothing visible yet) while no score of the tile exceeds it by more than kLazySlack: the common tile has no cross-lane
+// exchange, no alpha and no rescale; l_part is this LANE's share of the row's sum (rowgroup_sum once, after the loop).
+// Masking is a real branch (the uniform need_mask test used to be if-converted: 16 selects, 22 compares and 24 scalar
+// ands on EVERY tile — ~60 of the fp8 body's ~380 instructions per tile, a loop SQ counters show issue-bound).
+template <int DT>
+__device__ __forceinline__ void softmax_tile(const f32x4& s0, const f32x4& s1, bool need_mask, bool row_ok, int tt,
+                                             int g, int t_end, int limit, int wnd, float scale_log2, float inv_scale,
+                                             float& m_run, float& l_part, f32x4 (&o)[DT], bf16x8& pf, bf16x8& pl) {
+  float sc[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sc[e] = s0[e];
+    sc[4 + e] = s1[e];
+  }
+  if (need_mask) {
+    asm volatile("" ::: "memory");   // keeps this a branch: the block is rare and long
+#pragma unroll
+    for (int th = 0; th < 2; ++th)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int tok = tt + 16 * th + 4 * g + e;
+        if (!(row_ok && tok < t_end && tok <= limit && tok > limit - wnd)) sc[th * 4 + e] = -INFINITY;
+      }
+  }
+  const float lmax = max3f(max3f(max3f(sc[0], sc[1], sc[2]), sc[3], sc[4]), sc[5], max_nc(sc[6], sc[7]));
+  // raw score above which the row must adopt a new maximum (-inf while nothing is visible: any finite score then does)
+  const float thr = __builtin_fmaf(m_run, inv_scale, kLazySlack * inv_scale);
+  if (__any(lmax > thr)) {
+    const float tmax = rowgroup_max(lmax);
+    const float m_new = fmaxf(m_run, tmax * scale_log2);
+    const float m_to = m_new == -INFINITY ? 0.0f : m_new;   // nothing visible yet: exponents against 0 (all scores are -inf)
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_to);
+    m_run = m_new;
+    l_part *= alpha;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] *= alpha;
+  }
+  const float m_use = m_run == -INFINITY ? 0.0f : m_run;
+  float pv[8], p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e], scale_log2, -m_use));
+    if (e & 1) p1 += pv[e];
+    else p0 += pv[e];
+  }
+  l_part += p0 + p1;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    pf[e] = static_cast<__bf16>(pv[e]);
+    pl[e] = static_cast<__bf16>(pv[e] - static_cast<float>(pf[e]));
+  }
 }
 
 // softmax_tile for the long-draft kernel: the scale is folded into the exponent's fma (the maximum is taken on
@@ -410,6 +411,7 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
   const_i32_ptr btab = (const_i32_ptr)(P.block_table + static_cast<int64_t>(req) * P.max_blocks);
   const int bs = P.block_size;  // multiple of 16: a 16-token group never straddles two pages
   const float scale_log2 = P.sm_scale * kLog2e * (KV8 ? *P.k_scale : 1.0f);
+  const float inv_scale = 1.0f / scale_log2;
   const float out_scale = KV8 ? *P.v_scale : 1.0f;
   constexpr int ES = KV8 ? 1 : 2;  // bytes per cache element
   const char* kc = reinterpret_cast<const char*>(P.k_cache);
@@ -441,7 +443,7 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
     if (P.sinks != nullptr && part == 0) {      // the row's first partial starts from the sink: (max, sum) = (sink, 1)
       const int rc = min(row0 + mt * 16 + c16, n_rows - 1);
       m_run[mt] = P.sinks[h * G + (rc - (rc / G) * G)] * kLog2e;      // log2 domain, like the scaled scores
-      l_run[mt] = 1.0f;                         // (l_run is the row's sum, replicated over the row's four lanes)
+      l_run[mt] = g == 0 ? 1.0f : 0.0f;         // (inside the loop l_run is this lane's share of the row's sum: one lane carries the 1)
     }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) o_acc[mt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -601,7 +603,7 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
 #pragma unroll
       for (int mt = 0; mt < MTQ; ++mt) {
         softmax_tile<DT>(st[mt][0], st[mt][1], need_mask, row_ok[mt], tt, g, t_end, ctx - q_len + row_pos[mt], wnd, scale_log2,
-                     m_run[mt], l_run[mt], o_acc[mt], pfrag[mt], pfrag_lo[mt]);
+                         inv_scale, m_run[mt], l_run[mt], o_acc[mt], pfrag[mt], pfrag_lo[mt]);
       }
 
       // 5. O^T += V^T P^T : A = V^T fragment via transposing LDS reads
@@ -629,6 +631,9 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
     }
   }
   AIC_PSTAMP(4)
+  // the loop kept per-lane shares of the rows' sums: from here on l_run is the row's sum on each of its four lanes
+#pragma unroll
+  for (int mt = 0; mt < MTQ; ++mt) l_run[mt] = rowgroup_sum(l_run[mt]);
 
 #undef AIC_LOAD_K
 #undef AIC_LOAD_V
