@@ -243,55 +243,6 @@ __device__ __forceinline__ void softmax_tile(const f32x4& s0, const f32x4& s1, b
   }
 }
 
-// softmax_tile for the long-draft kernel: the scale is folded into the exponent's fma (the maximum is taken on
-// raw scores; m_run is kept scaled), the row sum stays a per-lane partial (rowgroup_sum once, in the epilogue).
-__device__ __forceinline__ void softmax_tile_long(const f32x4& s0, const f32x4& s1, bool need_mask, bool row_ok, int tt,
-                                                  int g, int t_end, int limit, float scale_log2, float& m_run,
-                                                  float& l_part, f32x4 (&o)[8], bf16x8& pf, bf16x8& pl) {
-  float sc[8];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    sc[e] = s0[e];
-    sc[4 + e] = s1[e];
-  }
-  if (need_mask) {
-#pragma unroll
-    for (int th = 0; th < 2; ++th)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int tok = tt + 16 * th + 4 * g + e;
-        if (!(row_ok && tok < t_end && tok <= limit)) sc[th * 4 + e] = -INFINITY;
-      }
-  }
-  const float tmax = rowgroup_max(fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])),
-                                        fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7]))));
-  const float m_new = fmaxf(m_run, tmax * scale_log2);
-  float alpha = 1.0f, psum = 0.0f;
-  float pv[8];
-  if (m_new == -INFINITY) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) pv[e] = 0.0f;
-  } else {
-    alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e], scale_log2, -m_new));
-      psum += pv[e];
-    }
-  }
-  l_part = l_part * alpha + psum;
-  m_run = m_new;
-  if (!__all(alpha == 1.0f)) {
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) o[dt] *= alpha;
-  }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    pf[e] = static_cast<__bf16>(pv[e]);
-    pl[e] = static_cast<__bf16>(pv[e] - static_cast<float>(pf[e]));
-  }
-}
-
 // 8 e4m3 bytes (two dwords) -> 8 bf16 (exact: every e4m3 value is a bf16 value).  gfx950's scaled converts take two
 // fp8 to two bf16 in ONE instruction (v_cvt_scalef32_pk_bf16_fp8, scale 1.0): 4 VALU per 8 elements where the
 // fp8 -> f32 -> bf16 route took 8.  SQ counters on the fp8 short body (profiles/r02_pmc_secondary_kernels.txt): 70.8 % of
