@@ -1028,6 +1028,60 @@ def test_verify_attention_mixed_call_forms_agree(seed):
         N.check(N.lib().aic_debug_attn_sequential(-1))
 
 
+@pytest.mark.parametrize("shape", ["rising", "falling", "spikes", "plateaus"])
+@pytest.mark.parametrize("fp8", [False, True])
+def test_verify_attention_lazy_maximum_on_structured_scores(shape, fp8):
+    """Both attention bodies keep a row's adopted maximum while no score exceeds it by more than 2^6 (lazy maximum): scores that
+    RISE tile after tile (every tile takes the exact path), FALL (the first tile's maximum stays: weights down to 2^-120),
+    SPIKE (isolated tokens far above a flat floor, at random tiles) or sit on PLATEAUS just below the slack (weights up to 2^6
+    before a row adopts a new maximum) must give the oracle's attention — short requests, LSTM-length and suffix-length drafts."""
+    torch.manual_seed(3)
+    B, Hq, Hkv, D, bs = 6, 32, 8, 128, 16
+    q_lens = [1, 4, 33, 20, 1, 9]
+    ctxs = [1500, 700, 2100, 900, 64, 333]
+    q, kc, vc, bt, qsl = _attn_case(B, Hq, Hkv, D, q_lens, ctxs, bs, seed=23)
+    # keys = a common direction u times a per-token profile (+ a little noise), queries = c * u: score(t) ~ c * profile(t)
+    g = torch.Generator().manual_seed(5)
+    u = torch.randn(D, generator=g)
+    u = u / u.norm()
+    nb = kc.shape[0]
+    tok = torch.arange(nb * bs).view(nb, bs).float()           # a key's profile follows its SLOT: contexts walk random pages, so
+    for i, c in enumerate(ctxs):                               # give every request's tokens their position through the block table
+        pos = torch.arange(c)
+        slot = bt[i, pos // bs].long() * bs + pos % bs
+        tok.view(-1)[slot] = pos.float()
+    t = tok / 2100.0
+    if shape == "rising":
+        prof = 40.0 * t
+    elif shape == "falling":
+        prof = -40.0 * t
+    elif shape == "spikes":
+        prof = torch.where(torch.rand(nb, bs, generator=g) < 0.01, torch.full((nb, bs), 30.0), torch.zeros(nb, bs))
+    else:
+        prof = torch.floor(t * 12.0) * 1.7        # steps of 1.7 * c * scale in the exponent: several steps below the slack, then over it
+    kc = (prof[..., None, None] * u + 0.05 * torch.randn(nb, bs, Hkv, D, generator=g)).to(torch.bfloat16)
+    q = (3.0 * u + 0.05 * torch.randn(q.shape, generator=g)).to(torch.bfloat16) * (D ** 0.5 / 3.0)
+    scale = D ** -0.5
+    kw = {}
+    if fp8:
+        ks = float(kc.float().abs().max()) / 448.0
+        vs = float(vc.float().abs().max()) / 448.0
+        kc8 = O.fp8_sat(kc.float() / ks, "e4m3")
+        vc8 = O.fp8_sat(vc.float() / vs, "e4m3")
+        want = O.verify_attention(q, kc8, vc8, bt, ctxs, qsl, scale, ks, vs)
+        kw = dict(k_scale=torch.tensor([ks], device=DEV), v_scale=torch.tensor([vs], device=DEV))
+        kc_dev, vc_dev = kc8.to(DEV), vc8.to(DEV)
+    else:
+        want = O.verify_attention(q, kc, vc, bt, ctxs, qsl, scale)
+        kc_dev, vc_dev = kc.to(DEV), vc.to(DEV)
+    seq = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
+    for host_lens in (None, q_lens):
+        got = _ops().verify_attention(q.to(DEV), kc_dev, vc_dev, bt.to(DEV), seq, torch.tensor(qsl, device=DEV), max(q_lens), max(ctxs),
+                                      scale, q_lens_host=host_lens, **kw).float().cpu()
+        assert torch.isfinite(got).all()
+        assert torch.allclose(got, want, atol=1e-3, rtol=2 ** -8), (shape, fp8, host_lens is not None, (got - want).abs().max())
+
+
 def test_verify_attention_long_draft_dma_duty_patterns():
     """Who issues the tile DMA in a long-draft workgroup is a choice (aic_debug_attn_long_dma: every wave its quarter / the waves
     with one row tile more issue nothing / they keep their K pieces / wave 0 keeps one piece): every pattern must give the same
