@@ -1383,7 +1383,8 @@ __device__ __forceinline__ void verify_attn_long4_body(const AttnParams& P, uint
   if constexpr (TR) {
     if (P.ptrace && lane == 0) {
       const uint64_t c_end = __builtin_amdgcn_s_memtime();
-      int64_t* r = P.ptrace + (((static_cast<int64_t>(bz) * gridDim.y + by) * gridDim.x + bx) * 4 + wave) * 16;
+      const int nx_ = P.ptrace_stride & 0xffff, ny_ = P.ptrace_stride >> 16;   // the long part's grid (x, y): set by the host
+      int64_t* r = P.ptrace + (((static_cast<int64_t>(bz) * ny_ + by) * nx_ + bx) * 4 + wave) * 16;
       r[0] = static_cast<int64_t>(c_loop - c_entry);   // prologue: geometry, Q rows, first tiles issued
       r[1] = static_cast<int64_t>(c_end - c_loop);     // the tile loop
       r[2] = static_cast<int64_t>(cyc[0]);
@@ -1438,7 +1439,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 // workgroups still sit beside the short ones on the CUs (both bodies are 4 waves, <= 256 VGPRs, 64 KiB LDS: two
 // workgroups per CU), and they come first in the grid so that they are placed before the CUs fill up.
 // The long part is padded to a multiple of 8 workgroups (idle ones), which keeps the short body's XCD-aware item mapping.
-template <int HPW, bool KV8, int MTQ>
+template <int HPW, bool KV8, int MTQ, bool TR = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 verify_attn_pair_kernel(AttnParams PS, AttnParams PL, int n_long_wg, int n_long_pad, int long_x, int long_y, int short_x) {
   constexpr int kShortU4 = ShortLds<MTQ == 0 ? 2 : MTQ, 4>::kU4;
@@ -1450,7 +1451,7 @@ verify_attn_pair_kernel(AttnParams PS, AttnParams PL, int n_long_wg, int n_long_
     if (b < n_long_wg) {
       const int x = b % long_x, yz = b / long_x;
       const int y = yz % long_y, z = yz / long_y;
-      verify_attn_long4_body<KV8, 128>(PL, lds, x, y, z);
+      verify_attn_long4_body<KV8, 128, TR>(PL, lds, x, y, z);   // (TR: the diagnostic cycle account, tools/microbench.py mixphases)
     }
   } else {
     const int sb = b - n_long_pad;
@@ -2001,7 +2002,12 @@ int aic_verify_attention_win(const void* q, int64_t q_stride, const void* k_cach
       P.trace = (g_attn_trace && static_cast<int>(pgrid.x) <= g_attn_trace_cap) ? g_attn_trace : nullptr;
 #define AIC_PAIR_LAUNCH(HPW_, KV8_)                                                                             \
   launch(verify_attn_pair_kernel<HPW_, KV8_, 0>, pgrid, dim3(256), s, P, PL, n_long_wg, n_long_pad, long_x, n_splits_long, short_x);
-      if (hpw == 4) {
+      if (g_attn_ptrace && hpw == 4 && !kv8 && n_long_wg * 8 <= g_attn_ptrace_cap && long_x < 65536) {
+        // debug: the long workgroups of a MIXED call keep the per-wave cycle account (tools/microbench.py mixphases)
+        PL.ptrace = g_attn_ptrace;
+        PL.ptrace_stride = long_x | (n_splits_long << 16);
+        launch(verify_attn_pair_kernel<4, false, 0, true>, pgrid, dim3(256), s, P, PL, n_long_wg, n_long_pad, long_x, n_splits_long, short_x);
+      } else if (hpw == 4) {
         if (kv8) { AIC_PAIR_LAUNCH(4, true) } else { AIC_PAIR_LAUNCH(4, false) }
       } else if (hpw == 2) {
         if (kv8) { AIC_PAIR_LAUNCH(2, true) } else { AIC_PAIR_LAUNCH(2, false) }
@@ -2033,6 +2039,7 @@ int aic_verify_attention_win(const void* q, int64_t q_stride, const void* k_cach
       dim3 grid(static_cast<unsigned>(n_long * num_kv_heads), n_splits_long, (max_rows + per_block_rows - 1) / per_block_rows);
       if (g_attn_ptrace && !d64 && !kv8 && n_short == 0 && static_cast<int>(grid.x * grid.y * grid.z) * 8 <= g_attn_ptrace_cap) {
         PL.ptrace = g_attn_ptrace;   // debug: per-wave cycle accounting of a long-only call (tools/microbench.py longphases)
+        PL.ptrace_stride = static_cast<int>(grid.x) | (static_cast<int>(grid.y) << 16);
         launch(verify_attn_long4_kernel<false, 128, true>, grid, dim3(256), s, PL);
       } else if (d64)
         launch(verify_attn_long4_kernel<false, 64>, grid, dim3(256), overlap ? side->stream : s, PL);

@@ -227,13 +227,15 @@ def attn_phases(n_short=32, ctx=4224, kv8=False, Hq=32, Hkv=8, D=128, bs=16):
           f"last end - median end {us(t[:, 5].max() - np.median(t[:, 5])):.1f} us")
 
 
-def attn_long_phases(B=16, q_long=33, ctx=4096, Hq=32, Hkv=8, D=128, bs=16):
-    """Shader-clock cycle accounting of the long-draft body per wave (aic_debug_attn_phase_trace on a long-only call)."""
+def attn_long_phases(B=16, q_long=33, ctx=4096, Hq=32, Hkv=8, D=128, bs=16, n_short=0):
+    """Shader-clock cycle accounting of the long-draft body per wave (aic_debug_attn_phase_trace on a long-only call, or —
+    n_short > 0 — on the long workgroups of a mixed call, which share their CUs with short-request workgroups)."""
     nblk = (ctx + bs - 1) // bs
-    nb = B * nblk
+    nb = (B + n_short) * nblk
     kv = torch.randn(2, nb, bs, Hkv, D, device=dev, dtype=torch.bfloat16)
-    bt = torch.randperm(nb, device=dev).to(torch.int32).view(B, nblk)
-    ql = [q_long] * B
+    bt = torch.randperm(nb, device=dev).to(torch.int32).view(B + n_short, nblk)
+    ql = [1] * n_short + [q_long] * B
+    B = B + n_short
     q = torch.randn(sum(ql), Hq, D, device=dev, dtype=torch.bfloat16)
     seq = torch.full((B,), ctx, dtype=torch.int32, device=dev)
     qsl = torch.tensor(np.concatenate([[0], np.cumsum(ql)]).astype(np.int32), device=dev)
@@ -252,7 +254,7 @@ def attn_long_phases(B=16, q_long=33, ctx=4096, Hq=32, Hkv=8, D=128, bs=16):
     dur_us = (t[:, 7] - t[:, 10]) / 100.0
     ghz = float(np.median(t[:, 11] / np.maximum(dur_us, 1e-3))) / 1e3
     start = (t[:, 10] - t[:, 10].min()) / 100.0
-    print(f"long-phases B={B} x {q_long} tokens, ctx {ctx}: call {us:.1f} us (traced build {us_tr:.1f} us); {len(t) // 4} workgroups, "
+    print(f"long-phases {n_short} short + {B - n_short} x {q_long} tokens, ctx {ctx}: call {us:.1f} us (traced build {us_tr:.1f} us); {len(t) // 4} workgroups, "
           f"{int(np.median(n_iter))} KV tiles each; shader clock {ghz:.2f} GHz; wave start after the first: median {np.median(start):.1f} "
           f"max {start.max():.1f} us; wave duration min / median / max {dur_us.min():.1f} / {np.median(dur_us):.1f} / {dur_us.max():.1f} us")
     print("   cycles per KV tile and wave, by the wave's row tiles (MFMA issue is asynchronous: a phase that needs results waits for them)")
@@ -357,6 +359,10 @@ if __name__ == "__main__":
             attn_mix(31, 1, q_long=33)
             attn_mix(28, 4, q_long=20)
         N.lib().aic_debug_attn_long_dma(1)
+    if "mixphases" in what:   # the same account for the long workgroups of mixed calls (one lane of the bench)
+        attn_long_phases(1, 33, 4224, n_short=31)
+        attn_long_phases(1, 10, 4224, n_short=31)
+        attn_long_phases(4, 20, 4224, n_short=28)
     if "longphases" in what:  # cycle accounting of the long-draft body
         attn_long_phases(16, 33)
         attn_long_phases(16, 20)
@@ -465,6 +471,13 @@ if __name__ == "__main__":
         attn_mix(59, 5, kv8=True)
         attn_mix(8, 1, Hq=4, Hkv=1)      # SP = 8 slice
         attn_mix(59, 5, Hq=4, Hkv=1)
+    if "mixdma" in what:        # DMA duty pattern of the long part of mixed calls
+        for pat in (0, 1, 2):
+            N.lib().aic_debug_attn_long_dma(pat)
+            print(f"-- long_dma pattern {pat}")
+            for ns, nl, ql in ((31, 1, 10), (30, 2, 10), (31, 1, 20), (31, 1, 33), (30, 2, 33), (28, 4, 20), (27, 5, 33)):
+                attn_mix(ns, nl, q_long=ql)
+        N.lib().aic_debug_attn_long_dma(1)
     if "mixes" in what:         # the bench's common lane mixes under the library's own rules
         attn(B=32, ctx=4224, qlen=1, split=True)
         for ns, nl, ql in ((31, 1, 10), (30, 2, 10), (31, 1, 20), (30, 2, 20), (31, 1, 33), (30, 2, 33), (28, 4, 20), (27, 5, 33), (25, 7, 20)):
