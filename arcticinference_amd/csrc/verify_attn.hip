@@ -320,12 +320,24 @@ __device__ __forceinline__ void verify_attn_body(const AttnParams& P, uint4* v_l
   const int row_group = (bx >> 3) % m_groups;
   if (item >= P.n_items) return;
   const int ridx = item / hgroups;
-  const int req = __builtin_amdgcn_readfirstlane(P.req_list ? P.req_list[ridx] : ridx);
+  // The request's geometry is two dependent lookups (list entry -> offsets and length), ~0.7 us of every workgroup's start.  A
+  // list of short requests is usually the identity (a lane step without a long draft): the entry's geometry is requested
+  // together with the entry, as if it were, and read again only when the entry says otherwise.
+  int req = ridx, q0 = P.query_start_loc[ridx], q1 = P.query_start_loc[ridx + 1], ctx = P.seq_lens[ridx];
+  if (P.req_list) {
+    req = P.req_list[ridx];
+    if (req != ridx) {
+      q0 = P.query_start_loc[req];
+      q1 = P.query_start_loc[req + 1];
+      ctx = P.seq_lens[req];
+    }
+  }
+  req = __builtin_amdgcn_readfirstlane(req);
+  q0 = __builtin_amdgcn_readfirstlane(q0);
+  ctx = __builtin_amdgcn_readfirstlane(ctx);
+  const int q_len = __builtin_amdgcn_readfirstlane(q1) - q0;
   const int head_local = wave / R, range = wave - head_local * R;
   const int h = (item - ridx * hgroups) * HPW + head_local;
-  const int q0 = __builtin_amdgcn_readfirstlane(P.query_start_loc[req]);
-  const int q_len = __builtin_amdgcn_readfirstlane(P.query_start_loc[req + 1]) - q0;
-  const int ctx = __builtin_amdgcn_readfirstlane(P.seq_lens[req]);
   const int n_rows = q_len * G;
   const int row0 = row_group * (MTQ * 16);
   if (row0 >= n_rows) return;
